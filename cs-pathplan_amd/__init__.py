@@ -1,0 +1,294 @@
+"""cs-pathplan_amd -- MI355X-native batched minimum-snap solver (Python binding of the C-ABI).
+
+The directory name carries a hyphen, so import it with
+
+    import importlib; csp = importlib.import_module("cs-pathplan_amd")
+
+This module is a thin ctypes layer over libcsp_minsnap.so (include/csp_minsnap.h).  It is used
+by tests/, bench.py and the torch.distributed sharding helper; the drop-in for the reference's
+C++ callers is the class shim in host/minimum_snap.hpp.
+
+There is NO CPU fallback: importing fails loudly when the HIP extension has not been built,
+and every solve call raises when no gfx950 device is visible.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+try:
+    # Must precede the CDLL below.  torch bundles its own libamdhip64.so.7; if ours (linked to
+    # /opt/rocm) were loaded first the process would hold two HIP runtimes and torch would then
+    # report "No HIP GPUs are available".  Loading torch first makes both share one runtime.
+    import torch  # noqa: F401
+except ImportError:  # the C-ABI itself does not need torch (host-memory calls, C++ callers)
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsp_minsnap.so")
+
+ABI_VERSION = 1
+DTYPE_F64, DTYPE_F32 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_FORCE_GENERIC = 0x1
+TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
+
+EXPORTED_SYMBOLS = (
+    "csp_minsnap_solve_batch", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
+    "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
+    "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
+)
+
+
+class CspError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("csp_minsnap error %d (%s)%s" % (code, strerror(code), (": " + detail) if detail else ""))
+
+
+class Desc(ctypes.Structure):
+    """Mirror of `csp_minsnap_desc` (include/csp_minsnap.h)."""
+    _fields_ = [
+        ("abi_version", ctypes.c_uint32), ("dtype", ctypes.c_uint32),
+        ("order", ctypes.c_int32), ("num_segments", ctypes.c_int32),
+        ("batch", ctypes.c_int64),
+        ("seg_offsets", ctypes.c_void_p),
+        ("max_segments", ctypes.c_int32), ("bc_per_trajectory", ctypes.c_uint32),
+        ("path_weight", ctypes.c_double), ("vel_zero_weight", ctypes.c_double),
+        ("vel_zero_weight_per_traj", ctypes.c_void_p),
+        ("mem_space", ctypes.c_uint32), ("device_id", ctypes.c_int32),
+        ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+    ]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cs-pathplan_amd: %s is missing.  Build the HIP extension first "
+        "(python cs-pathplan_amd/build.py, or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+
+_lib = ctypes.CDLL(LIB_PATH)
+_lib.csp_minsnap_solve_batch.restype = ctypes.c_int
+_lib.csp_minsnap_solve_batch.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
+_lib.csp_minsnap_workspace_bytes.restype = ctypes.c_size_t
+_lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
+_lib.csp_minsnap_time_alloc_batch.restype = ctypes.c_int
+_lib.csp_minsnap_time_alloc_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+_lib.csp_minsnap_kernel_name.restype = ctypes.c_char_p
+_lib.csp_minsnap_kernel_name.argtypes = [ctypes.POINTER(Desc)]
+_lib.csp_minsnap_device_count.restype = ctypes.c_int
+_lib.csp_minsnap_version.restype = ctypes.c_char_p
+_lib.csp_minsnap_strerror.restype = ctypes.c_char_p
+_lib.csp_minsnap_strerror.argtypes = [ctypes.c_int]
+_lib.csp_minsnap_last_hip_error.restype = ctypes.c_char_p
+
+
+def raw_lib():
+    return _lib
+
+
+def version():
+    return _lib.csp_minsnap_version().decode()
+
+
+def strerror(code):
+    return _lib.csp_minsnap_strerror(int(code)).decode()
+
+
+def device_count():
+    return int(_lib.csp_minsnap_device_count())
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _np_dtype(dtype_code):
+    return np.float32 if dtype_code == DTYPE_F32 else np.float64
+
+
+def make_desc(order, batch, num_segments=0, dtype=DTYPE_F64, path_weight=0.0, vel_zero_weight=0.0,
+              mem_space=MEM_HOST, bc_per_trajectory=False, seg_offsets_ptr=None, max_segments=0,
+              vw_per_ptr=None, device_id=-1, flags=0):
+    d = Desc()
+    d.abi_version = ABI_VERSION
+    d.dtype = dtype
+    d.order = int(order)
+    d.num_segments = int(num_segments)
+    d.batch = int(batch)
+    d.seg_offsets = seg_offsets_ptr
+    d.max_segments = int(max_segments)
+    d.bc_per_trajectory = 1 if bc_per_trajectory else 0
+    d.path_weight = float(path_weight)
+    d.vel_zero_weight = float(vel_zero_weight)
+    d.vel_zero_weight_per_traj = vw_per_ptr
+    d.mem_space = mem_space
+    d.device_id = int(device_id)
+    d.flags = int(flags)
+    d.reserved = 0
+    return d
+
+
+def workspace_bytes(desc):
+    return int(_lib.csp_minsnap_workspace_bytes(ctypes.byref(desc)))
+
+
+def kernel_name(desc):
+    r = _lib.csp_minsnap_kernel_name(ctypes.byref(desc))
+    return r.decode() if r else None
+
+
+def _check(rc):
+    if rc != 0:
+        raise CspError(rc, _lib.csp_minsnap_last_hip_error().decode() if rc == -4 or rc == -5 else "")
+
+
+class Result:
+    __slots__ = ("coeffs", "max_dev", "status", "kernel")
+
+    def __init__(self, coeffs, max_dev, status, kernel):
+        self.coeffs, self.max_dev, self.status, self.kernel = coeffs, max_dev, status, kernel
+
+
+def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
+                seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
+                want_max_dev=False, want_status=False, out=None, workspace=None, stream=None,
+                force_generic=False):
+    """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
+
+    numpy inputs  -> CSP_MEM_HOST (staged through the device, synchronous);
+    torch CUDA tensors -> CSP_MEM_DEVICE (enqueued on `stream` or torch's current stream).
+    Uniform batches: waypoints [B,S+1,3], times [B,S]; ragged: pass seg_offsets [B+1] (int64)
+    with concatenated waypoints [sum(S_b+1),3] and times [sum S_b].
+    bc: [4,3] / [1,4,3] shared or [B,4,3] per trajectory; rows start vel, end vel, start acc,
+    end acc (reference Vel/Acc); None = zeros (MinimumSnapConfig defaults, minimum_snap.hpp:29-32).
+    Returns Result(coeffs [B,S,3,2o] (ragged: [sum S_b,3,2o]), max_dev, status, kernel name).
+    """
+    on_device = _is_torch(waypoints)
+    ragged = seg_offsets is not None
+    flags = FLAG_FORCE_GENERIC if force_generic else 0
+    m = 2 * int(order)
+    if on_device:
+        import torch
+        if not waypoints.is_cuda:
+            raise ValueError("torch inputs must be CUDA tensors (use numpy arrays for host memory)")
+        tdt = waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        dev = waypoints.device
+        waypoints, times = waypoints.contiguous(), times.to(tdt).contiguous()
+        if ragged:
+            seg_offsets = seg_offsets.to(device=dev, dtype=torch.int64).contiguous()
+            B = seg_offsets.numel() - 1
+            total = times.numel()
+            if max_segments is None:
+                max_segments = int((seg_offsets[1:] - seg_offsets[:-1]).max().item()) if B else 1
+            S = 0
+        else:
+            B, S = times.shape
+            total = B * S
+        if bc is None:
+            bc = torch.zeros((1, 4, 3), dtype=tdt, device=dev)
+        bc = bc.to(tdt).contiguous().reshape(-1, 4, 3)
+        if bc.shape[0] not in (1, B):
+            raise ValueError("bc must be [4,3], [1,4,3] or [B,4,3]")
+        per = bc.shape[0] == B
+        if out is None:
+            out = torch.empty((total, 3, m) if ragged else (B, S, 3, m), dtype=tdt, device=dev)
+        md = torch.empty(B, dtype=torch.float64, device=dev) if want_max_dev else None
+        stt = torch.empty(B, dtype=torch.int32, device=dev) if want_status else None
+        vwp = None
+        if vel_zero_weight_per_traj is not None:
+            vwp = vel_zero_weight_per_traj.to(device=dev, dtype=torch.float64).contiguous()
+        desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, per,
+                         seg_offsets.data_ptr() if ragged else None, max_segments or 0,
+                         vwp.data_ptr() if vwp is not None else None,
+                         dev.index if dev.index is not None else -1, flags)
+        need = workspace_bytes(desc)
+        if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        rc = _lib.csp_minsnap_solve_batch(
+            ctypes.byref(desc), waypoints.data_ptr(), times.data_ptr(), bc.data_ptr(), out.data_ptr(),
+            md.data_ptr() if md is not None else None, stt.data_ptr() if stt is not None else None,
+            workspace.data_ptr() if need else None, need, ctypes.c_void_p(st))
+        _check(rc)
+        return Result(out, md, stt, kernel_name(desc))
+
+    # host memory
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    waypoints = np.ascontiguousarray(waypoints, dtype=npdt)
+    times = np.ascontiguousarray(times, dtype=npdt)
+    if ragged:
+        seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.int64)
+        B = seg_offsets.shape[0] - 1
+        total = times.shape[0]
+        if max_segments is None:
+            max_segments = int(np.max(np.diff(seg_offsets))) if B else 1
+        S = 0
+    else:
+        B, S = times.shape
+        total = B * S
+    bc = np.zeros((1, 4, 3), dtype=npdt) if bc is None else np.ascontiguousarray(bc, dtype=npdt).reshape(-1, 4, 3)
+    if bc.shape[0] not in (1, B):
+        raise ValueError("bc must be [4,3], [1,4,3] or [B,4,3]")
+    per = bc.shape[0] == B
+    if out is None:
+        out = np.empty((total, 3, m) if ragged else (B, S, 3, m), dtype=npdt)
+    md = np.empty(B, dtype=np.float64) if want_max_dev else None
+    stt = np.empty(B, dtype=np.int32) if want_status else None
+    vwp = None
+    if vel_zero_weight_per_traj is not None:
+        vwp = np.ascontiguousarray(vel_zero_weight_per_traj, dtype=np.float64)
+    desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_HOST, per,
+                     seg_offsets.ctypes.data if ragged else None, max_segments or 0,
+                     vwp.ctypes.data if vwp is not None else None, -1, flags)
+    rc = _lib.csp_minsnap_solve_batch(
+        ctypes.byref(desc), waypoints.ctypes.data, times.ctypes.data, bc.ctypes.data, out.ctypes.data,
+        md.ctypes.data if md is not None else None, stt.ctypes.data if stt is not None else None,
+        None, 0, None)
+    _check(rc)
+    return Result(out, md, stt, kernel_name(desc))
+
+
+def time_alloc_batch(waypoints, v_avg, min_time_s, seg_offsets=None, stream=None):
+    """Batched T_i = max(|dp_i|/V_avg, min_time_s) (math_util/minimum_snap.cpp:63-72)."""
+    ragged = seg_offsets is not None
+    if _is_torch(waypoints):
+        import torch
+        dev, tdt = waypoints.device, waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        waypoints = waypoints.contiguous()
+        if ragged:
+            seg_offsets = seg_offsets.to(device=dev, dtype=torch.int64).contiguous()
+            B = seg_offsets.numel() - 1
+            times = torch.empty(waypoints.shape[0] - B, dtype=tdt, device=dev)
+            S = 0
+        else:
+            B, S = waypoints.shape[0], waypoints.shape[1] - 1
+            times = torch.empty((B, S), dtype=tdt, device=dev)
+        desc = make_desc(1, B, S, dtype, mem_space=MEM_DEVICE,
+                         seg_offsets_ptr=seg_offsets.data_ptr() if ragged else None, max_segments=1 if ragged else 0,
+                         device_id=dev.index if dev.index is not None else -1)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        _check(_lib.csp_minsnap_time_alloc_batch(ctypes.byref(desc), waypoints.data_ptr(), float(v_avg),
+                                                 float(min_time_s), times.data_ptr(), ctypes.c_void_p(st)))
+        return times
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    waypoints = np.ascontiguousarray(waypoints, dtype=npdt)
+    if ragged:
+        seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.int64)
+        B = seg_offsets.shape[0] - 1
+        times = np.empty(waypoints.shape[0] - B, dtype=npdt)
+        S = 0
+    else:
+        B, S = waypoints.shape[0], waypoints.shape[1] - 1
+        times = np.empty((B, S), dtype=npdt)
+    desc = make_desc(1, B, S, dtype, mem_space=MEM_HOST,
+                     seg_offsets_ptr=seg_offsets.ctypes.data if ragged else None, max_segments=1 if ragged else 0)
+    _check(_lib.csp_minsnap_time_alloc_batch(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg),
+                                             float(min_time_s), times.ctypes.data, None))
+    return times

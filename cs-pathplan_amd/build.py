@@ -1,0 +1,53 @@
+"""In-tree build of libcsp_minsnap.so (HIP kernels + C-ABI) for gfx950.
+
+    python cs-pathplan_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The shared object stays next to this file so it travels
+with the repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcsp_minsnap.so")
+SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_fixed.hip", "minsnap_timealloc.hip"]
+HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_tables.h",
+           os.path.join("..", "..", "include", "csp_minsnap.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not (force or _stale()):
+        return LIB
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host_check(out=None):
+    """Compiles the C++ class shim (host/minimum_snap.hpp, host/bezier.hpp) against the bundled
+    mini matrix type and links it with the C-ABI library: the 'does the drop-in compile' check."""
+    out = out or os.path.join(HERE, "host", "shim_selftest")
+    src = os.path.join(HERE, "host", "shim_selftest.cpp")
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(HERE, "..", "include"),
+           "-I", os.path.join(HERE, "host"), src, "-o", out, "-L", HERE, "-lcsp_minsnap",
+           "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,255 @@
+// minsnap_capi.hip -- implementation of the C-ABI in include/csp_minsnap.h.
+// Host-side validation, workspace carving, host<->device staging for CSP_MEM_HOST callers and
+// kernel dispatch.  No CPU compute path exists: every entry point ends in a HIP launch or an
+// error code.
+#include "../../include/csp_minsnap.h"
+#include "minsnap_launch.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+int hip_fail(hipError_t e, const char *what) {
+    g_last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return CSP_ERR_HIP;
+}
+#define CSP_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Shape {
+    bool f32, ragged;
+    int order, S, Smax;
+    int64_t B;
+    size_t elt;
+};
+
+int validate(const csp_minsnap_desc *d, Shape &s) {
+    if (!d) return CSP_ERR_INVALID_ARG;
+    if (d->abi_version != CSP_MINSNAP_ABI_VERSION) return CSP_ERR_INVALID_ARG;
+    if (d->dtype != CSP_DTYPE_F64 && d->dtype != CSP_DTYPE_F32) return CSP_ERR_INVALID_ARG;
+    if (d->mem_space != CSP_MEM_HOST && d->mem_space != CSP_MEM_DEVICE) return CSP_ERR_INVALID_ARG;
+    if (d->order < 1) return CSP_ERR_INVALID_ARG;
+    if (d->order > 5) return CSP_ERR_UNSUPPORTED;
+    if (d->batch < 0 || d->num_segments < 0) return CSP_ERR_INVALID_ARG;
+    if (d->path_weight < 0.0 || d->vel_zero_weight < 0.0) return CSP_ERR_INVALID_ARG;
+    s.f32 = d->dtype == CSP_DTYPE_F32;
+    s.elt = s.f32 ? 4 : 8;
+    s.order = d->order;
+    s.B = d->batch;
+    s.ragged = d->num_segments == 0;
+    if (s.ragged) {
+        if (!d->seg_offsets || d->max_segments < 1) return CSP_ERR_INVALID_ARG;
+        s.S = 0;
+        s.Smax = d->max_segments;
+    } else {
+        s.S = s.Smax = d->num_segments;
+    }
+    return CSP_OK;
+}
+
+bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
+    if (d->flags & CSP_FLAG_FORCE_GENERIC) return false;
+    return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged);
+}
+
+size_t ws_bytes(const csp_minsnap_desc *d, const Shape &s, size_t *tstar_off) {
+    if (use_fixed(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
+    size_t factors = align_up((size_t)(s.Smax > 1 ? s.Smax - 1 : 0) * csp::generic_ws_entries(s.order) *
+                                  (size_t)s.B * s.elt, 256);
+    if (tstar_off) *tstar_off = factors;
+    size_t ts = d->path_weight > 0.0 ? align_up((size_t)s.Smax * (size_t)s.B * sizeof(int), 256) : 0;
+    return factors + ts;
+}
+
+int select_device(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CSP_ERR_NO_DEVICE;
+    if (device_id >= n) return CSP_ERR_INVALID_ARG;
+    if (device_id >= 0) CSP_HIP(hipSetDevice(device_id));
+    int cur = 0;
+    CSP_HIP(hipGetDevice(&cur));
+    hipDeviceProp_t p;
+    CSP_HIP(hipGetDeviceProperties(&p, cur));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        g_last_hip_error = std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only";
+        return CSP_ERR_NO_DEVICE;
+    }
+    return CSP_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { CSP_HIP(hipMalloc(&p, n ? n : 1)); return CSP_OK; }
+};
+
+int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const void *tm, const void *bc,
+             void *co, double *max_dev, int32_t *status, const int64_t *seg_off, const double *vw_per,
+             void *ws, size_t ws_size, hipStream_t st) {
+    size_t tstar_off = 0;
+    const size_t need = ws_bytes(d, s, &tstar_off);
+    if (need > 0 && (!ws || ws_size < need)) return CSP_ERR_WORKSPACE;
+    csp::GenericArgs a;
+    a.wp = wp; a.times = tm; a.bc = bc; a.coeffs = co; a.max_dev = max_dev; a.status = status;
+    a.seg_off = s.ragged ? seg_off : nullptr;
+    a.ws = ws;
+    a.tstar = d->path_weight > 0.0 ? (int *)((char *)ws + tstar_off) : nullptr;
+    a.vw_per = vw_per;
+    a.path_weight = d->path_weight;
+    a.vel_zero_weight = d->vel_zero_weight;
+    a.B = s.B; a.S = s.S; a.order = s.order; a.bc_per_traj = d->bc_per_trajectory ? 1 : 0;
+    hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, st);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return CSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *csp_minsnap_version(void) { return "csp-minsnap 0.1.0 (gfx950, abi 1)"; }
+
+const char *csp_minsnap_strerror(int st) {
+    switch (st) {
+        case CSP_OK: return "ok";
+        case CSP_ERR_INVALID_ARG: return "invalid argument";
+        case CSP_ERR_UNSUPPORTED: return "unsupported order (reference int arithmetic overflows from order 6)";
+        case CSP_ERR_WORKSPACE: return "workspace missing or too small";
+        case CSP_ERR_HIP: return "HIP runtime error";
+        case CSP_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback exists)";
+    }
+    return "unknown status";
+}
+
+const char *csp_minsnap_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int csp_minsnap_device_count(void) {
+    int n = 0, good = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++good;
+    }
+    return good;
+}
+
+size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc) {
+    Shape s;
+    if (validate(desc, s) != CSP_OK) return 0;
+    return ws_bytes(desc, s, nullptr);
+}
+
+const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
+    static thread_local char name[64];
+    Shape s;
+    if (validate(desc, s) != CSP_OK) return nullptr;
+    if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.S);
+    std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order, s.f32 ? "f32" : "f64", s.ragged ? "_ragged" : "");
+    return name;
+}
+
+int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
+                            const void *bc, void *coeffs, double *max_dev, int32_t *status,
+                            void *workspace, size_t workspace_bytes, void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+
+    if (desc->mem_space == CSP_MEM_DEVICE)
+        return dispatch(desc, s, waypoints, times, bc, coeffs, max_dev, status, desc->seg_offsets,
+                        desc->vel_zero_weight_per_traj, workspace, workspace_bytes, st);
+
+    // CSP_MEM_HOST: stage through the device, synchronously.
+    int64_t total_seg;
+    if (s.ragged) {
+        total_seg = desc->seg_offsets[s.B];
+        for (int64_t b = 0; b < s.B; ++b) {
+            const int64_t n = desc->seg_offsets[b + 1] - desc->seg_offsets[b];
+            if (n < 0 || n > s.Smax) return CSP_ERR_INVALID_ARG;
+        }
+    } else {
+        total_seg = s.B * (int64_t)s.S;
+    }
+    const size_t m = 2 * (size_t)s.order;
+    const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
+    const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt;
+    const size_t n_co = (size_t)total_seg * 3 * m * s.elt;
+    const size_t n_ws = ws_bytes(desc, s, nullptr);
+    DevBuf d_wp, d_tm, d_bc, d_co, d_md, d_st, d_so, d_vw, d_ws;
+    if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm)) || (rc = d_bc.alloc(n_bc)) ||
+        (rc = d_co.alloc(n_co)) || (rc = d_ws.alloc(n_ws)))
+        return rc;
+    if (max_dev && (rc = d_md.alloc((size_t)s.B * 8))) return rc;
+    if (status && (rc = d_st.alloc((size_t)s.B * 4))) return rc;
+    CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
+    CSP_HIP(hipMemcpyAsync(d_tm.p, times, n_tm, hipMemcpyHostToDevice, st));
+    CSP_HIP(hipMemcpyAsync(d_bc.p, bc, n_bc, hipMemcpyHostToDevice, st));
+    if (s.ragged) {
+        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
+        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
+    }
+    if (desc->vel_zero_weight_per_traj) {
+        if ((rc = d_vw.alloc((size_t)s.B * 8))) return rc;
+        CSP_HIP(hipMemcpyAsync(d_vw.p, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyHostToDevice, st));
+    }
+    rc = dispatch(desc, s, d_wp.p, d_tm.p, d_bc.p, d_co.p, (double *)d_md.p, (int32_t *)d_st.p,
+                  (const int64_t *)d_so.p, (const double *)d_vw.p, d_ws.p, n_ws, st);
+    if (rc != CSP_OK) return rc;
+    CSP_HIP(hipMemcpyAsync(coeffs, d_co.p, n_co, hipMemcpyDeviceToHost, st));
+    if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, d_md.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
+    if (status) CSP_HIP(hipMemcpyAsync(status, d_st.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
+    CSP_HIP(hipStreamSynchronize(st));
+    return CSP_OK;
+}
+
+int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg,
+                                 double min_time_s, void *times, void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !times) return CSP_ERR_INVALID_ARG;
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    csp::TimeAllocArgs a;
+    a.B = s.B; a.S = s.S; a.v_avg = v_avg; a.min_time_s = min_time_s;
+    if (desc->mem_space == CSP_MEM_DEVICE) {
+        a.wp = waypoints; a.times = times; a.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+        hipError_t e = csp::launch_time_alloc(a, s.f32, st);
+        return e == hipSuccess ? CSP_OK : hip_fail(e, "time_alloc launch");
+    }
+    const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
+    DevBuf d_wp, d_tm, d_so;
+    if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm))) return rc;
+    CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
+    if (s.ragged) {
+        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
+        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
+    }
+    a.wp = d_wp.p; a.times = d_tm.p; a.seg_off = (const int64_t *)d_so.p;
+    hipError_t e = csp::launch_time_alloc(a, s.f32, st);
+    if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
+    CSP_HIP(hipMemcpyAsync(times, d_tm.p, n_tm, hipMemcpyDeviceToHost, st));
+    CSP_HIP(hipStreamSynchronize(st));
+    return CSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// minsnap_launch.h -- host-visible launch interface between the C-ABI (minsnap_capi.hip) and
+// the kernels (minsnap_generic.hip, minsnap_fixed.hip).  Internal; the public boundary is
+// include/csp_minsnap.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace csp {
+
+struct GenericArgs {
+    const void *wp;         // [B][S+1][3] (or ragged concatenation)
+    const void *times;      // [B][S]
+    const void *bc;         // [B or 1][4][3]
+    void *coeffs;           // [B][S][3][2o]
+    double *max_dev;        // [B] or null
+    int32_t *status;        // [B] or null
+    const int64_t *seg_off; // ragged prefix sums or null
+    void *ws;               // [(Smax-1)][n*n+3n][B] reals
+    int *tstar;             // [Smax][B] (path penalty only) or null
+    const double *vw_per;   // [B] or null
+    double path_weight;
+    double vel_zero_weight;
+    int64_t B;
+    int S;                  // uniform S (ignored when seg_off != null)
+    int order;
+    int bc_per_traj;
+};
+
+hipError_t launch_generic(const GenericArgs &a, bool f32, hipStream_t st);
+size_t generic_ws_entries(int order);
+
+// Fixed-size register-resident kernel (minsnap_fixed.hip).  Serves order 4, f64, uniform even
+// S in {2,4,..,16}, penalties off or zero-velocity only.
+bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged);
+hipError_t launch_fixed(const GenericArgs &a, hipStream_t st);
+const char *fixed_kernel_name(int S);
+
+struct TimeAllocArgs {
+    const void *wp;
+    void *times;
+    const int64_t *seg_off;
+    int64_t B;
+    int S;
+    double v_avg, min_time_s;
+};
+hipError_t launch_time_alloc(const TimeAllocArgs &a, bool f32, hipStream_t st);
+
+}  // namespace csp

@@ -1,0 +1,123 @@
+/*
+ * csp_minsnap.h -- C-ABI of the MI355X-native batched minimum-snap solver.
+ *
+ * This is the drop-in boundary for ONE hot path of MEZHANGYUE/CS-PathPlan: the closed-form
+ * minimum-snap QP behind `TrajectoryGeneratorTool` (reference interface:
+ * math_util/minimum_snap.hpp:36-63; implementation math_util/minimum_snap.cpp:22-649).
+ * The reference is a C++ class with Eigen types in its signatures; a C++ shim with the same
+ * class surface (cs-pathplan_amd/host/minimum_snap.hpp) forwards to the entry points below, so
+ * `UavPathPlanner::Minisnap_3D/Minisnap_EN` (uavPathPlanning.cpp:4401-4474) compile unchanged.
+ * See INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions shared by every entry point
+ *   - plain pointers and sizes only; caller owns every buffer; nothing throws across the ABI;
+ *   - return value: CSP_OK (0) or a negative csp_status; per-trajectory problems are reported
+ *     through the optional `status` array, never by aborting the batch;
+ *   - silent: nothing is printed (the reference prints inside the solver);
+ *   - thread-safe for distinct streams; no global mutable state besides the lazily built
+ *     constant tables;
+ *   - the compute path is HIP on gfx950 only.  There is NO CPU fallback: without a usable
+ *     device the calls return CSP_ERR_NO_DEVICE.
+ *
+ * Data layout (all row-major, contiguous)
+ *   waypoints : [B][S+1][3]   positions (reference `Path`, W x 3, minimum_snap.hpp:47)
+ *   times     : [B][S]        segment durations (reference `Time`, minimum_snap.hpp:50)
+ *   bc        : [B or 1][4][3] rows = start vel, end vel, start acc, end acc
+ *                             (reference `Vel` 2x3 and `Acc` 2x3, minimum_snap.hpp:48-49)
+ *   coeffs    : [B][S][3][2*order]  polynomial coefficients per segment and axis, HIGHEST power
+ *               first, local time t in [0, T_seg] -- the row-major image of the reference's
+ *               PolyCoeff (S x 3*p_num1d, minimum_snap.cpp:220-223, :626-648)
+ *   ragged batches (num_segments == 0): trajectories are concatenated; trajectory b owns
+ *               segments seg_offsets[b] .. seg_offsets[b+1]-1 of `times`/`coeffs` and waypoints
+ *               seg_offsets[b]+b .. seg_offsets[b+1]+b of `waypoints`.
+ */
+#ifndef CSP_MINSNAP_H_
+#define CSP_MINSNAP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSP_MINSNAP_ABI_VERSION 1u
+
+typedef enum csp_status {
+    CSP_OK = 0,
+    CSP_ERR_INVALID_ARG = -1, /* null pointer, bad order/segment count, bad abi_version      */
+    CSP_ERR_UNSUPPORTED = -2, /* order outside 1..5 (the reference's int arithmetic overflows
+                                 from order 6, minimum_snap.cpp:321-323)                      */
+    CSP_ERR_WORKSPACE = -3,   /* workspace missing or smaller than csp_minsnap_workspace_bytes */
+    CSP_ERR_HIP = -4,         /* a HIP runtime call failed; see csp_minsnap_last_hip_error    */
+    CSP_ERR_NO_DEVICE = -5    /* no gfx950 device visible -- there is no CPU fallback         */
+} csp_status;
+
+enum { CSP_DTYPE_F64 = 0, CSP_DTYPE_F32 = 1 };
+enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
+
+/* flags */
+#define CSP_FLAG_FORCE_GENERIC 0x1u /* never dispatch the register-resident fixed-size kernel */
+
+/* per-trajectory status bits written to `status` */
+#define CSP_TRAJ_OK 0
+#define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently) */
+#define CSP_TRAJ_NOT_SPD 2     /* a pivot of the free-derivative Hessian R_PP was <= 0              */
+
+typedef struct csp_minsnap_desc {
+    uint32_t abi_version;       /* CSP_MINSNAP_ABI_VERSION                                       */
+    uint32_t dtype;             /* CSP_DTYPE_F64 | CSP_DTYPE_F32: type of waypoints/times/bc/coeffs */
+    int32_t order;              /* derivative order d_order (reference `order`): 4 = min-snap,
+                                   polynomial degree 2*order-1 (minimum_snap.cpp:237-238)         */
+    int32_t num_segments;       /* uniform S >= 1, or 0 for a ragged batch                         */
+    int64_t batch;              /* B >= 0                                                          */
+    const int64_t *seg_offsets; /* ragged only: [B+1] prefix sums, same memory space as the data   */
+    int32_t max_segments;       /* ragged only: max_b S_b (sizes the workspace)                    */
+    uint32_t bc_per_trajectory; /* 0: bc is [1][4][3] shared by the batch; 1: [B][4][3]            */
+    double path_weight;         /* reference `path_weight` (minimum_snap.cpp:233, :347-469)        */
+    double vel_zero_weight;     /* reference `vel_zero_weight` (:234, :473-509)                    */
+    const double *vel_zero_weight_per_traj; /* optional [B] (always f64) overriding the scalar;
+                                   used by the batched re-solve loop (minimum_snap.cpp:80-90)      */
+    uint32_t mem_space;         /* CSP_MEM_HOST: pointers are host memory, the call stages through
+                                   the device and is synchronous; CSP_MEM_DEVICE: device pointers,
+                                   the call only enqueues work on `hip_stream`                     */
+    int32_t device_id;          /* HIP device ordinal; -1 = current device                         */
+    uint32_t flags;
+    uint32_t reserved;
+} csp_minsnap_desc;
+
+/* Replaces TrajectoryGeneratorTool::SolveQPClosedForm (math_util/minimum_snap.hpp:45-53,
+ * minimum_snap.cpp:227-649) for a batch of independent trajectories.
+ *   max_dev : optional [B] f64, the reference's *max_deviation out-parameter per trajectory
+ *   status  : optional [B] i32, CSP_TRAJ_* bits
+ *   workspace / workspace_bytes : device scratch of at least csp_minsnap_workspace_bytes(desc)
+ *             bytes (CSP_MEM_DEVICE); may be NULL/0 with CSP_MEM_HOST (allocated internally)
+ *   hip_stream : hipStream_t (NULL = default stream) */
+int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
+                            const void *bc, void *coeffs, double *max_dev, int32_t *status,
+                            void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* Device scratch bytes the call above needs for `desc` (0 when the fixed-size kernel serves it). */
+size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
+
+/* Replaces the time-allocation step of TrajectoryGeneratorTool::GenerateTrajectoryMatrix
+ * (minimum_snap.cpp:59-72): T_i = max(|p_{i+1}-p_i| / V_avg, min_time_s), or min_time_s when
+ * V_avg <= 1e-6.  Same layouts / descriptor as the solve (path/vel weights ignored). */
+int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg,
+                                 double min_time_s, void *times, void *hip_stream);
+
+/* Name of the kernel csp_minsnap_solve_batch would dispatch for `desc` ("fixed_o4_s16_f64",
+ * "generic_o4_f64", ...); NULL for an invalid descriptor.  For tests and profiles. */
+const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc);
+
+/* Number of visible HIP devices whose architecture is gfx950 (0 => every solve call fails). */
+int csp_minsnap_device_count(void);
+
+const char *csp_minsnap_version(void);
+const char *csp_minsnap_strerror(int status);
+const char *csp_minsnap_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSP_MINSNAP_H_ */

@@ -1,0 +1,131 @@
+"""CPU oracle for the minimum-snap hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product path (cs-pathplan_amd/) never does.  PARITY UNPINNED: see dense_oracle.c header.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcsp_oracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    """Compile dense_oracle.c (gcc) if the shared object is missing or stale."""
+    src = os.path.join(_HERE, "dense_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        for name in ("csp_oracle_solve", "csp_oracle_ld_solve"):
+            f = getattr(L, name)
+            f.restype = ctypes.c_int
+            f.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.c_double,
+                          ctypes.c_double, _dp, _dp]
+        for name in ("csp_oracle_solve_batch", "csp_oracle_ld_solve_batch"):
+            f = getattr(L, name)
+            f.restype = ctypes.c_int
+            f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int,
+                          ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.c_int]
+        L.csp_oracle_time_alloc.restype = ctypes.c_int
+        L.csp_oracle_time_alloc.argtypes = [ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double, _dp]
+        L.csp_oracle_generate_trajectory.restype = ctypes.c_long
+        L.csp_oracle_generate_trajectory.argtypes = [
+            ctypes.c_int, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+            ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.c_long, _dp, _dp, _dp]
+        L.csp_oracle_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def solve(order, path, vel, acc, time, path_weight=0.0, vel_zero_weight=0.0, long_double=False):
+    """One SolveQPClosedForm call.  Returns (coeff [S, 3*2o], max_dev)."""
+    path, vel, acc, time = _c(path), _c(vel, (2, 3)), _c(acc, (2, 3)), _c(time)
+    S = time.shape[0]
+    assert path.shape == (S + 1, 3)
+    coeff = np.zeros((S, 3 * 2 * order))
+    md = ctypes.c_double(0.0)
+    fn = lib().csp_oracle_ld_solve if long_double else lib().csp_oracle_solve
+    rc = fn(order, S, _p(path), _p(vel), _p(acc), _p(time), path_weight, vel_zero_weight,
+            _p(coeff), ctypes.byref(md))
+    if rc:
+        raise ValueError("csp_oracle_solve rc=%d" % rc)
+    return coeff, md.value
+
+
+def solve_batch(order, waypoints, times, bc=None, path_weight=0.0, vel_zero_weight=0.0,
+                nthreads=1, long_double=False):
+    """waypoints [B,S+1,3], times [B,S], bc [B or 1,4,3] (rows v0,v1,a0,a1) or None (zeros).
+    Returns (coeffs [B,S,3,2o], max_dev [B])."""
+    waypoints, times = _c(waypoints), _c(times)
+    B, S = times.shape
+    assert waypoints.shape == (B, S + 1, 3)
+    if bc is None:
+        bc = np.zeros((1, 4, 3))
+    bc = _c(bc)
+    bcast = 1 if bc.shape[0] == 1 and B != 1 or bc.shape[0] == 1 else 0
+    coeff = np.zeros((B, S, 3, 2 * order))
+    md = np.zeros(B)
+    fn = lib().csp_oracle_ld_solve_batch if long_double else lib().csp_oracle_solve_batch
+    rc = fn(order, S, B, _p(waypoints), _p(times), _p(bc), bcast, path_weight, vel_zero_weight,
+            _p(coeff), _p(md), int(nthreads))
+    if rc:
+        raise ValueError("csp_oracle_solve_batch rc=%d" % rc)
+    return coeff, md
+
+
+def time_alloc(path, v_avg, min_time_s):
+    path = _c(path)
+    T = np.zeros(path.shape[0] - 1)
+    lib().csp_oracle_time_alloc(path.shape[0], _p(path), v_avg, min_time_s, _p(T))
+    return T
+
+
+def generate_trajectory(path, order=3, path_weight=0.0, vel_zero_weight=0.0, v_avg=5.0,
+                        min_time_s=0.1, sample_distance=1.0, bc=None, cap=1 << 20):
+    path = _c(path)
+    W = path.shape[0]
+    bc = _c(np.zeros((4, 3)) if bc is None else bc)
+    samples = np.zeros((cap, 3))
+    S = max(W - 1, 1)
+    coeff = np.zeros((S, 3, 2 * order))
+    T = np.zeros(S)
+    stats = np.zeros(5)
+    n = lib().csp_oracle_generate_trajectory(W, _p(path), order, path_weight, vel_zero_weight, v_avg,
+                                             min_time_s, sample_distance, _p(bc), _p(samples), cap,
+                                             _p(coeff), _p(T), _p(stats))
+    if n < 0:
+        return np.zeros((0, 0)), {}
+    assert n <= cap
+    return samples[:n].copy(), {"coeff": coeff, "time": T, "vel_zero_weight": stats[0],
+                                "iters": int(stats[1]), "max_dev": stats[2],
+                                "max_climb_rate": stats[3], "min_turn_radius": stats[4]}
+
+
+def max_threads():
+    return int(lib().csp_oracle_max_threads())
