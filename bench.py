@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- minimum-snap solves/sec on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (csp_minsnap_solve_batch through the C-ABI) over one
+batch of synthetic trajectories already resident in HBM.  Workload = BASELINE config C3 per GPU:
+B=65536 independent 3-axis trajectories, 16 segments, order 4 (degree 7), fp64.  Trajectories
+are independent, so ranks shard the batch with no data-path collective (weak scaling: every
+rank owns 65536 trajectories of one deterministic stream).
+
+One JSON line on rank 0; `roofline` prices the dominant kernel against the 8 TB/s HBM peak by
+ALGORITHMIC bytes (3608 B/solve at S=16,o=4,f64 -- SURVEY.md §8d); `cpu_baseline` times the CPU
+oracle (a restatement of the reference's dense path, kind "port") on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests import synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(order, S, wp, tm, budget_s):
+    """Oracle (dense restatement, kind 'port') on all host cores over a bounded sample."""
+    import oracle
+    oracle.build()
+    threads = oracle.max_threads()
+    probe = min(4 * threads, wp.shape[0])
+    t0 = time.perf_counter()
+    oracle.solve_batch(order, wp[:probe], tm[:probe], nthreads=threads)
+    per = (time.perf_counter() - t0) / probe
+    n = int(min(wp.shape[0], max(probe, budget_s / max(per, 1e-9))))
+    t0 = time.perf_counter()
+    ref, _ = oracle.solve_batch(order, wp[:n], tm[:n], nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": threads, "kind": "port",
+            "sample": "%d of the %d trajectories of the timed batch, dense LU restatement "
+                      "(oracle/dense_oracle.c, -O2, OpenMP), %.1f s" % (n, wp.shape[0], dt)}, ref, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--segments", type=int, default=16)
+    ap.add_argument("--order", type=int, default=4)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-generic", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    csp = importlib.import_module("cs-pathplan_amd")
+    B, S, o = args.batch, args.segments, args.order
+    wp, tm = synth.make_batch(B, S, config_id=3, offset=rank * B)
+    d_wp, d_tm = torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev)
+    d_bc = torch.zeros((1, 4, 3), dtype=torch.float64, device=dev)
+    out = torch.empty((B, S, 3, 2 * o), dtype=torch.float64, device=dev)
+    desc = csp.make_desc(o, B, S, csp.DTYPE_F64, mem_space=csp.MEM_DEVICE,
+                         flags=csp.FLAG_FORCE_GENERIC if args.force_generic else 0)
+    ws_bytes = csp.workspace_bytes(desc)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    kernel = csp.kernel_name(desc)
+
+    def step():
+        csp.solve_batch(d_wp, d_tm, d_bc, order=o, out=out, workspace=ws, force_generic=args.force_generic)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        bytes_per_solve = synth.algorithmic_bytes(S, o, 8)
+        solves_per_s = world * B * args.steps / elapsed
+        achieved = B * bytes_per_solve / (kernel_ms * 1e-3) / 1e9  # GB/s, one launch on one GPU
+        traffic = None
+        tr_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tr_file):
+            try:
+                tr = json.load(open(tr_file))
+                if tr.get("kernel") == kernel and tr.get("batch") == B:
+                    traffic = tr.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "minimum-snap solves/sec (16-seg, order-7, 3-axis)",
+            "value": solves_per_s, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: B=%d trajectories/GPU x %d segments, order %d (degree %d), "
+                                   "3 axes, fp64, zero boundary vel/acc, penalties off" % (B, S, o, 2 * o - 1),
+                       "batch_per_gpu": B, "segments": S, "order": o, "kernel": kernel,
+                       "sharding": "independent trajectories per rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_solve": bytes_per_solve, "kernel": kernel,
+                         "kernel_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref, n = cpu_baseline(o, S, wp, tm, args.cpu_budget)
+            res["cpu_baseline"] = cb
+            chk = min(n, 1024)
+            res["parity_max_rel_err"] = synth.rel_err(out[:chk].cpu().numpy(), ref[:chk])
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,381 @@
-// minsnap_fixed.hip -- register-resident fixed-size kernel (placeholder until the kernel lands).
+// minsnap_fixed.hip -- register-resident kernel for the headline buckets
+// (order 4 = minimum snap, fp64, uniform even S <= 16, no path penalty).
+//
+// Mapping: a trajectory is split at its middle waypoint between two WAVES of one
+// workgroup.  Wave 0 ("top") eliminates interior waypoints 1..S/2-1 downwards, wave 1
+// ("bottom") runs the very same code on the time-reversed second half (reversed waypoint order,
+// odd derivatives negated), i.e. a twisted block-LDL^T factorisation of the block-tridiagonal
+// R_PP (minimum_snap.cpp:564-566).  Lane l of both waves owns trajectory 64*block+l, so every
+// value a lane needs later (W_k = S_k^-1 C_k and z_k = S_k^-1 y_k, 18 doubles per waypoint) stays
+// in ITS registers -- nothing is spilled to memory between the forward and the backward sweep.
+// The two halves meet once, through 15 doubles per lane in LDS: each side's Schur carry onto
+// the middle waypoint.  The roles are wave-uniform, so the only divergence is a scalar branch.
+//
+// Algorithmic HBM traffic per trajectory: 8*(3(S+1)+S) bytes in, 8*24*S bytes out
+// (S=16: 536 + 3072 = 3608 B); no workspace.
+#include "minsnap_device.h"
 #include "minsnap_launch.h"
+
 namespace csp {
-bool fixed_supported(int, int, bool, double, bool) { return false; }
-hipError_t launch_fixed(const GenericArgs &, hipStream_t) { return hipErrorNotSupported; }
-const char *fixed_kernel_name(int) { return "fixed_unavailable"; }
+
+namespace {
+
+using T4 = Tab<4>;
+constexpr int O4 = 4;
+constexpr int M8 = 8;
+
+// Scaled per-segment constants for order 4 (free derivatives r = 1..3 -> index r-1).
+// ee[r][c] = (-1)^(r+c) ss[r][c] and Qt[.][end pos] = -Qt[.][start pos] (checked in
+// tests/test_tables.py), so only ss, se and the two position columns are formed.
+struct Seg4 {
+    double ss[3][3];  // symmetric; full storage keeps the unrolled code simple
+    double se[3][3];
+    double sp[3];     // Qt[start r][start pos]
+    double ep[3];     // Qt[end r][start pos]
+};
+
+__device__ __forceinline__ void seg4(double T, double vw, Seg4 &s) {
+    double ip[M8];
+    ip[0] = 1.0;
+    ip[1] = fast_rcp(T);
+#pragma unroll
+    for (int e = 2; e < M8; ++e) ip[e] = ip[e - 1] * ip[1];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s.ss[r][c] = T4::QT(r + 1, c + 1) * ip[5 - r - c];
+            s.se[r][c] = T4::QT(r + 1, O4 + c + 1) * ip[5 - r - c];
+        }
+        s.sp[r] = T4::QT(r + 1, 0) * ip[6 - r];
+        s.ep[r] = T4::QT(O4 + r + 1, 0) * ip[6 - r];
+    }
+    s.ss[0][0] += vw;  // zero-velocity penalty: +w on the velocity diagonal (minimum_snap.cpp:473-509)
 }
+
+__device__ __forceinline__ double ee_of(const Seg4 &s, int r, int c) {
+    return ((r + c) & 1) ? -s.ss[r][c] : s.ss[r][c];
+}
+
+// Inverse of a symmetric positive definite 3x3 via cofactors and one reciprocal.
+// Returns false when a leading minor is not positive.
+__device__ __forceinline__ bool inv3(const double (&S)[3][3], double (&I)[3][3]) {
+    const double a = S[0][0], b = S[1][0], c = S[1][1], d = S[2][0], e = S[2][1], f = S[2][2];
+    const double c00 = __builtin_fma(c, f, -e * e);
+    const double c10 = __builtin_fma(d, e, -b * f);
+    const double c20 = __builtin_fma(b, e, -c * d);
+    const double c11 = __builtin_fma(a, f, -d * d);
+    const double c21 = __builtin_fma(b, d, -a * e);
+    const double c22 = __builtin_fma(a, c, -b * b);
+    const double det = __builtin_fma(a, c00, __builtin_fma(b, c10, d * c20));
+    const double rd = fast_rcp(det);
+    I[0][0] = c00 * rd;
+    I[1][0] = I[0][1] = c10 * rd;
+    I[2][0] = I[0][2] = c20 * rd;
+    I[1][1] = c11 * rd;
+    I[2][1] = I[1][2] = c21 * rd;
+    I[2][2] = c22 * rd;
+    return (a > 0.0) && (c22 > 0.0) && (det > 0.0);
+}
+
+// Hermite -> monomial map for the 4 high coefficients (t^7..t^4) of one segment and axis.
+// xs/xe: free derivatives (vel, acc, jerk) at the segment's start/end in GLOBAL orientation,
+// dP = P_end - P_start, tp[r] = T^(r+1), ip[e] = T^-e.
+__device__ __forceinline__ void recover4(double Ps, double dP, const double (&xs)[3], const double (&xe)[3],
+                                         const double (&tp)[3], const double (&ip)[M8], double (&c)[M8]) {
+    double hs[3], he[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { hs[r] = xs[r] * tp[r]; he[r] = xe[r] * tp[r]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // G[i][0] + G[i][4] = 0 for the high rows: positions enter through dP only
+        double acc = T4::G(i, O4) * dP;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            acc = __builtin_fma(T4::G(i, r + 1), hs[r], acc);
+            acc = __builtin_fma(T4::G(i, O4 + r + 1), he[r], acc);
+        }
+        c[i] = acc * ip[7 - i];
+    }
+    c[4] = xs[2] * T4::G(4, 3);  // jerk / 3!
+    c[5] = xs[1] * T4::G(5, 2);  // acc / 2!
+    c[6] = xs[0];
+    c[7] = Ps;
+}
+
+template <int HS, bool BOTTOM>
+__device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool valid, int lane,
+                                           double (*xch)[15][64]) {
+    constexpr int S = 2 * HS;
+    const double *tm = (const double *)a.times + b * S;
+    const double *wp = (const double *)a.wp + b * (S + 1) * 3;
+    const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
+
+    // ---- local (role-oriented) inputs, fetched where they are used (the bottom role walks the
+    // trajectory backwards); keeping all of them live would push the factors out of registers ----
+    auto Tl = [&](int j) { return tm[BOTTOM ? S - 1 - j : j]; };
+    auto Pl = [&](int j, int ax) { return wp[(BOTTOM ? S - j : j) * 3 + ax]; };
+    const double vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
+
+    // boundary derivatives (minimum_snap.cpp:527-555): vel, acc given, jerk pinned to 0;
+    // time reversal negates odd derivatives
+    double z[3][3], W[3][3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        z[0][ax] = BOTTOM ? -bc[1 * 3 + ax] : bc[0 * 3 + ax];
+        z[1][ax] = BOTTOM ? bc[3 * 3 + ax] : bc[2 * 3 + ax];
+        z[2][ax] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) W[r][c] = 0.0;
+    double Wst[HS][3][3], zst[HS][3][3];  // slot k = local waypoint k (slot 0 unused)
+    bool spd = true;
+
+    // ---- forward elimination over local interior waypoints 1..HS-1 ----
+    Seg4 left, right;
+    seg4(Tl(0), vw, left);
+    double Pa[3], Pb[3], Pc[3];  // local waypoints k-1, k, k+1
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pl(0, ax); Pb[ax] = Pl(1, ax); }
+#pragma unroll
+    for (int k = 1; k < HS; ++k) {
+        seg4(Tl(k), vw, right);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) Pc[ax] = Pl(k + 1, ax);
+        double Sm[3][3], y[3][3], I[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double v = ee_of(left, r, c) + right.ss[r][c];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v = __builtin_fma(-left.se[j][r], W[j][c], v);
+                Sm[r][c] = v;
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+                v = __builtin_fma(right.sp[r], Pc[ax] - Pb[ax], v);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+                y[r][ax] = v;
+            }
+        }
+        spd &= inv3(Sm, I);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double w = I[r][0] * right.se[0][c];
+                w = __builtin_fma(I[r][1], right.se[1][c], w);
+                w = __builtin_fma(I[r][2], right.se[2][c], w);
+                W[r][c] = w;
+                Wst[k][r][c] = w;
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = I[r][0] * y[0][ax];
+                v = __builtin_fma(I[r][1], y[1][ax], v);
+                v = __builtin_fma(I[r][2], y[2][ax], v);
+                z[r][ax] = v;
+                zst[k][r][ax] = v;
+            }
+        }
+        left = right;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
+    }
+
+    // ---- Schur carry of this half onto the middle waypoint, exchanged through LDS ----
+    double Cm[3][3], cm[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            double v = ee_of(left, r, c);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v = __builtin_fma(-left.se[j][r], W[j][c], v);
+            Cm[r][c] = v;
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+            cm[r][ax] = v;
+        }
+    }
+    {
+        double(*mine)[64] = xch[BOTTOM ? 1 : 0];
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) mine[e++][lane] = Cm[r][c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) mine[e++][lane] = cm[r][ax];
+    }
+    __syncthreads();
+    double xm[3][3];
+    {
+        const double(*other)[64] = xch[BOTTOM ? 0 : 1];
+        double Sm[3][3], I[3][3];
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                const double o = other[e++][lane];
+                Sm[r][c] = Cm[r][c] + (((r + c) & 1) ? -o : o);
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double o = other[e++][lane];
+                cm[r][ax] += (r & 1) ? o : -o;  // derivative r+1 is odd for r = 0, 2
+            }
+        spd &= inv3(Sm, I);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = I[r][0] * cm[0][ax];
+                v = __builtin_fma(I[r][1], cm[1][ax], v);
+                v = __builtin_fma(I[r][2], cm[2][ax], v);
+                xm[r][ax] = v;
+            }
+    }
+
+    // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
+    double *co = (double *)a.coeffs + b * S * 24;
+    double nanacc = 0.0;
+    double xn[3][3];  // free derivatives at local waypoint j+1
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xm[r][ax];
+#pragma unroll
+    for (int j = HS - 1; j >= 0; --j) {
+        double xk[3][3];  // free derivatives at local waypoint j
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (j == 0) {
+                    xk[r][ax] = (r == 0) ? (BOTTOM ? -bc[1 * 3 + ax] : bc[0 * 3 + ax])
+                              : (r == 1) ? (BOTTOM ? bc[3 * 3 + ax] : bc[2 * 3 + ax]) : 0.0;
+                } else {
+                    double v = zst[j][r][ax];
+                    v = __builtin_fma(-Wst[j][r][0], xn[0][ax], v);
+                    v = __builtin_fma(-Wst[j][r][1], xn[1][ax], v);
+                    v = __builtin_fma(-Wst[j][r][2], xn[2][ax], v);
+                    xk[r][ax] = v;
+                }
+            }
+        const double Tj = Tl(j);
+        double ip[M8], tp[3];
+        ip[0] = 1.0;
+        ip[1] = fast_rcp(Tj);
+#pragma unroll
+        for (int e = 2; e < M8; ++e) ip[e] = ip[e - 1] * ip[1];
+        tp[0] = Tj;
+        tp[1] = Tj * Tj;
+        tp[2] = tp[1] * Tj;
+        const int g = BOTTOM ? S - 1 - j : j;  // global segment index
+        double *dst = co + g * 24;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double xs[3], xe[3], c[M8];
+            // global orientation: the bottom role's local start is the global END, and odd
+            // derivatives change sign back
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double sgn = (BOTTOM && !(r & 1)) ? -1.0 : 1.0;
+                xs[r] = BOTTOM ? sgn * xn[r][ax] : xk[r][ax];
+                xe[r] = BOTTOM ? sgn * xk[r][ax] : xn[r][ax];
+            }
+            const double Ps = BOTTOM ? Pl(j + 1, ax) : Pl(j, ax);
+            const double Pe = BOTTOM ? Pl(j, ax) : Pl(j + 1, ax);
+            recover4(Ps, Pe - Ps, xs, xe, tp, ip, c);
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < M8; i += 2) {
+                    double2 v2;
+                    v2.x = c[i];
+                    v2.y = c[i + 1];
+                    *reinterpret_cast<double2 *>(dst + ax * M8 + i) = v2;
+                }
+            }
+            if (a.status) {
+#pragma unroll
+                for (int i = 0; i < M8; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
+    }
+    if (a.status && valid) {
+        const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
+        if (bits) atomicOr(a.status + b, bits);
+    }
+}
+
+template <int HS>
+__global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
+    __shared__ double xch[2][15][64];
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;  // wave-uniform
+    int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = b < a.B;
+    if (!valid) b = a.B - 1;  // idle lanes redo the last trajectory and store nothing
+    if (role == 0) fixed_body<HS, false>(a, b, valid, lane, xch);
+    else fixed_body<HS, true>(a, b, valid, lane, xch);
+}
+
+}  // namespace
+
+bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged) {
+    return order == 4 && !f32 && !ragged && path_weight == 0.0 && S >= 2 && S <= 16 && (S % 2) == 0;
+}
+
+const char *fixed_kernel_name(int S) {
+    switch (S) {
+        case 2: return "fixed_o4_s2_f64";
+        case 4: return "fixed_o4_s4_f64";
+        case 6: return "fixed_o4_s6_f64";
+        case 8: return "fixed_o4_s8_f64";
+        case 10: return "fixed_o4_s10_f64";
+        case 12: return "fixed_o4_s12_f64";
+        case 14: return "fixed_o4_s14_f64";
+        case 16: return "fixed_o4_s16_f64";
+    }
+    return "fixed_unavailable";
+}
+
+hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
+    if (a.B == 0) return hipSuccess;
+    hipError_t e;
+    if (a.status && (e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.B, st)) != hipSuccess) return e;
+    // without the path penalty the reference's deviation metric is evaluated at t* = 0, where the
+    // polynomial equals its waypoint exactly (minimum_snap.cpp:342, :596-617)
+    if (a.max_dev && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
+    const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
+#define CSP_FIXED_CASE(hs) \
+    case 2 * hs: hipLaunchKernelGGL(minsnap_fixed_kernel<hs>, grid, block, 0, st, a); break;
+    switch (a.S) {
+        CSP_FIXED_CASE(1) CSP_FIXED_CASE(2) CSP_FIXED_CASE(3) CSP_FIXED_CASE(4)
+        CSP_FIXED_CASE(5) CSP_FIXED_CASE(6) CSP_FIXED_CASE(7) CSP_FIXED_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef CSP_FIXED_CASE
+    return hipGetLastError();
+}
+
+}  // namespace csp
