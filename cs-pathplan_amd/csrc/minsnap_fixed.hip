@@ -103,18 +103,31 @@ __device__ __forceinline__ void recover4(double Ps, double dP, const double (&xs
     c[7] = Ps;
 }
 
+// LDS geometry of one workgroup (64 trajectories, two waves)
+template <int HS> struct FixedLds {
+    static constexpr int S = 2 * HS;
+    static constexpr int WP_ROW = (S + 1) * 3;       // doubles per trajectory, unpadded (bank-clean for b64 reads)
+    static constexpr int TM_ROW = S + 2;             // doubles per trajectory, padded against bank conflicts
+    static constexpr int STAGE_ROW = 26;             // 24 coefficients + 2 pad doubles (208 B rows)
+    static constexpr int WP_DOUBLES = 64 * WP_ROW;
+    static constexpr int TM_DOUBLES = 64 * TM_ROW;
+    static constexpr int STAGE_DOUBLES = 64 * STAGE_ROW;  // per wave
+    static constexpr int XCH_DOUBLES = 2 * 15 * 64;
+    static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES + XCH_DOUBLES;
+};
+
 template <int HS, bool BOTTOM>
-__device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool valid, int lane,
+__device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
+                                           const double *l_wp, const double *l_tm, double *stage,
                                            double (*xch)[15][64]) {
     constexpr int S = 2 * HS;
-    const double *tm = (const double *)a.times + b * S;
-    const double *wp = (const double *)a.wp + b * (S + 1) * 3;
+    using L = FixedLds<HS>;
     const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
 
-    // ---- local (role-oriented) inputs, fetched where they are used (the bottom role walks the
-    // trajectory backwards); keeping all of them live would push the factors out of registers ----
-    auto Tl = [&](int j) { return tm[BOTTOM ? S - 1 - j : j]; };
-    auto Pl = [&](int j, int ax) { return wp[(BOTTOM ? S - j : j) * 3 + ax]; };
+    // ---- local (role-oriented) inputs come from the LDS image of the workgroup's 64 trajectories;
+    // the bottom role walks its half backwards ----
+    auto Tl = [&](int j) { return l_tm[lane * L::TM_ROW + (BOTTOM ? S - 1 - j : j)]; };
+    auto Pl = [&](int j, int ax) { return l_wp[lane * L::WP_ROW + (BOTTOM ? S - j : j) * 3 + ax]; };
     const double vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
 
     // boundary derivatives (minimum_snap.cpp:527-555): vel, acc given, jerk pinned to 0;
@@ -252,7 +265,6 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool
     }
 
     // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
-    double *co = (double *)a.coeffs + b * S * 24;
     double nanacc = 0.0;
     double xn[3][3];  // free derivatives at local waypoint j+1
 #pragma unroll
@@ -287,7 +299,6 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool
         tp[1] = Tj * Tj;
         tp[2] = tp[1] * Tj;
         const int g = BOTTOM ? S - 1 - j : j;  // global segment index
-        double *dst = co + g * 24;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             double xs[3], xe[3], c[M8];
@@ -302,26 +313,41 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool
             const double Ps = BOTTOM ? Pl(j + 1, ax) : Pl(j, ax);
             const double Pe = BOTTOM ? Pl(j, ax) : Pl(j + 1, ax);
             recover4(Ps, Pe - Ps, xs, xe, tp, ip, c);
-            if (valid) {
+            // lane-major staging tile: row = lane, 208-byte rows keep ds_write_b128 conflict-free
 #pragma unroll
-                for (int i = 0; i < M8; i += 2) {
-                    double2 v2;
-                    v2.x = c[i];
-                    v2.y = c[i + 1];
-                    *reinterpret_cast<double2 *>(dst + ax * M8 + i) = v2;
-                }
+            for (int i = 0; i < M8; i += 2) {
+                double2 v2;
+                v2.x = c[i];
+                v2.y = c[i + 1];
+                *reinterpret_cast<double2 *>(stage + lane * L::STAGE_ROW + ax * M8 + i) = v2;
             }
             if (a.status) {
 #pragma unroll
                 for (int i = 0; i < M8; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
             }
         }
+        // transposed read-back: consecutive lanes store consecutive 16-byte pieces, so one wave
+        // store covers 5.3 whole 192-byte (segment, trajectory) records instead of 64 slivers
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int q = i * 64 + lane;            // 16-byte piece index inside the wave's tile
+            const int row = (q * 43691) >> 19;      // q / 12 for q < 768
+            const int within = q - row * 12;
+            const double2 v2 = *reinterpret_cast<const double2 *>(stage + row * L::STAGE_ROW + within * 2);
+            if (b0 + row < a.B)
+                *reinterpret_cast<double2 *>((double *)a.coeffs + ((b0 + row) * S + g) * 24 + within * 2) = v2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
     }
-    if (a.status && valid) {
+    if (a.status && b0 + lane < a.B) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
     }
@@ -329,14 +355,49 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b, bool
 
 template <int HS>
 __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
-    __shared__ double xch[2][15][64];
-    const int lane = threadIdx.x & 63;
-    const int role = threadIdx.x >> 6;  // wave-uniform
-    int64_t b = (int64_t)blockIdx.x * 64 + lane;
-    const bool valid = b < a.B;
-    if (!valid) b = a.B - 1;  // idle lanes redo the last trajectory and store nothing
-    if (role == 0) fixed_body<HS, false>(a, b, valid, lane, xch);
-    else fixed_body<HS, true>(a, b, valid, lane, xch);
+    using L = FixedLds<HS>;
+    constexpr int S = 2 * HS;
+    __shared__ __attribute__((aligned(16))) double lds[L::TOTAL_DOUBLES];
+    double *l_wp = lds;
+    double *l_tm = l_wp + L::WP_DOUBLES;
+    double *l_stage = l_tm + L::TM_DOUBLES;
+    double(*xch)[15][64] = reinterpret_cast<double(*)[15][64]>(l_stage + 2 * L::STAGE_DOUBLES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int role = tid >> 6;  // wave-uniform
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+
+    // ---- coalesced copy-in: the workgroup's waypoints and times are contiguous in HBM ----
+    {
+        const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
+        const int n_wp = rows * L::WP_ROW / 2;  // 16-byte pieces (WP_ROW*64 is even; a ragged tail row count keeps it even too)
+        constexpr int WP_ITERS = (64 * L::WP_ROW / 2 + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < WP_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            if (c < n_wp) reinterpret_cast<double2 *>(l_wp)[c] = g_wp[c];
+        }
+        if ((rows * L::WP_ROW) & 1) {  // odd number of doubles: last one by itself
+            if (tid == 0) l_wp[rows * L::WP_ROW - 1] = ((const double *)a.wp + b0 * L::WP_ROW)[rows * L::WP_ROW - 1];
+        }
+        const double2 *g_tm = reinterpret_cast<const double2 *>((const double *)a.times + b0 * S);
+        const int n_tm = rows * HS;  // 16-byte pieces
+        constexpr int TM_ITERS = (64 * HS + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < TM_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            const int row = c / HS, col = c - row * HS;
+            if (c < n_tm) *reinterpret_cast<double2 *>(l_tm + row * L::TM_ROW + col * 2) = g_tm[c];
+        }
+    }
+    __syncthreads();
+
+    int64_t b = b0 + lane;
+    if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
+    if (role == 0) fixed_body<HS, false>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
+    else fixed_body<HS, true>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
 }
 
 }  // namespace
