@@ -27,7 +27,14 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True builds the DIAGNOSTIC library libcsp_minsnap_stamps.so (in-kernel s_memtime
+    stamps, never timed, never shipped) next to the product library."""
+    if stamps:
+        out = os.path.join(HERE, "libcsp_minsnap_stamps.so")
+        cmd = [HIPCC] + FLAGS + ["-DCSP_STAMPS", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+        subprocess.check_call(cmd)
+        return out
     if not (force or _stale()):
         return LIB
     cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
@@ -50,4 +57,7 @@ def build_host_check(out=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build(stamps=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

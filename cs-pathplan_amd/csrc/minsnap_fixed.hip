@@ -16,6 +16,25 @@
 #include "minsnap_device.h"
 #include "minsnap_launch.h"
 
+#ifdef CSP_STAMPS
+// Diagnostic build only (python cs-pathplan_amd/build.py --stamps): per-wave s_memtime stamps
+// written to a buffer nothing else reads.  The shipped library contains none of this.
+__device__ unsigned long long csp_g_stamps[8192 * 8];
+#define CSP_STAMP(slot)                                                                     \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                   \
+            csp_g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;          \
+    } while (0)
+extern "C" int csp_debug_read_stamps(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(csp_g_stamps), n * sizeof(unsigned long long));
+}
+#else
+#define CSP_STAMP(slot) do { } while (0)
+#endif
+
 namespace csp {
 
 namespace {
@@ -201,6 +220,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
     }
 
+    CSP_STAMP(2);
     // ---- Schur carry of this half onto the middle waypoint, exchanged through LDS ----
     double Cm[3][3], cm[3][3];
 #pragma unroll
@@ -233,6 +253,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
             for (int ax = 0; ax < 3; ++ax) mine[e++][lane] = cm[r][ax];
     }
     __syncthreads();
+    CSP_STAMP(3);
     double xm[3][3];
     {
         const double(*other)[64] = xch[BOTTOM ? 0 : 1];
@@ -347,6 +368,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
     }
+    CSP_STAMP(4);
     if (a.status && b0 + lane < a.B) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
@@ -369,6 +391,7 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
 
+    CSP_STAMP(0);
     // ---- coalesced copy-in: the workgroup's waypoints and times are contiguous in HBM ----
     {
         const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
@@ -393,6 +416,7 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
         }
     }
     __syncthreads();
+    CSP_STAMP(1);
 
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a wave of the fixed kernel spend its cycles?  Uses the stamps build
+(python cs-pathplan_amd/build.py --stamps).  Shares only -- never quote this build's run time."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import synth
+lib = ctypes.CDLL(os.path.join(ROOT, "cs-pathplan_amd", "libcsp_minsnap_stamps.so"))
+import importlib
+os.environ["CSP_LIB_OVERRIDE"] = "1"
+csp = importlib.import_module("cs-pathplan_amd")
+csp._lib = lib  # route the binding through the diagnostic library
+for f in ("csp_minsnap_solve_batch", "csp_minsnap_workspace_bytes", "csp_minsnap_kernel_name"):
+    getattr(lib, f).argtypes = getattr(csp.raw_lib(), f).argtypes if False else None
+lib.csp_minsnap_solve_batch.restype = ctypes.c_int
+lib.csp_minsnap_solve_batch.argtypes = [ctypes.POINTER(csp.Desc)] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
+lib.csp_minsnap_workspace_bytes.restype = ctypes.c_size_t
+lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(csp.Desc)]
+lib.csp_minsnap_kernel_name.restype = ctypes.c_char_p
+lib.csp_minsnap_kernel_name.argtypes = [ctypes.POINTER(csp.Desc)]
+B, S = 65536, 16
+wp, tm = synth.make_batch(B, S)
+d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+for _ in range(5):
+    csp.solve_batch(d_wp, d_tm, order=4)
+torch.cuda.synchronize()
+n = 4096 * 8
+buf = (ctypes.c_ulonglong * n)()
+lib.csp_debug_read_stamps(buf, n)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:4096, :5].astype(np.int64)
+d = np.diff(st, axis=1)
+names = ["copy-in+barrier", "forward sweep", "carry+exchange barrier", "mid solve+backward+stores"]
+tot = (st[:, 4] - st[:, 0])
+print("waves sampled:", len(st), " median wave lifetime (s_memtime ticks):", int(np.median(tot)))
+for i, nme in enumerate(names):
+    print("  %-28s median %8d  mean %8d  share %.1f%%" % (nme, np.median(d[:, i]), d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
+t0 = st[:, 0] - st[:, 0].min()
+print("kernel span (ticks):", int(st[:, 4].max() - st[:, 0].min()), " start-time spread p50/p90/max:", int(np.median(t0)), int(np.percentile(t0, 90)), int(t0.max()))
+print("top role lifetime median", int(np.median(tot[0::2])), " bottom", int(np.median(tot[1::2])))
