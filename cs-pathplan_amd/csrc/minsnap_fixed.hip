@@ -28,11 +28,18 @@ __device__ unsigned long long csp_g_stamps[8192 * 8];
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                   \
             csp_g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;          \
     } while (0)
+#define CSP_STAMP_RT(slot)                                                                  \
+    do {                                                                                    \
+        unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                           \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                   \
+            csp_g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;          \
+    } while (0)
 extern "C" int csp_debug_read_stamps(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(csp_g_stamps), n * sizeof(unsigned long long));
 }
 #else
 #define CSP_STAMP(slot) do { } while (0)
+#define CSP_STAMP_RT(slot) do { } while (0)
 #endif
 
 namespace csp {
@@ -135,7 +142,7 @@ template <int HS> struct FixedLds {
     static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES + XCH_DOUBLES;
 };
 
-template <int HS, bool BOTTOM>
+template <int HS, bool BOTTOM, bool STATUS, bool FULL>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
                                            const double *l_wp, const double *l_tm, double *stage,
                                            double (*xch)[15][64]) {
@@ -287,6 +294,14 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
     // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
     double nanacc = 0.0;
+    const int grp_raw = (lane * 43691) >> 19;      // lane / 12 (5 for lanes 60..63)
+    const int grp = grp_raw > 4 ? 4 : grp_raw;
+    const int lane_in = lane - grp_raw * 12 + (grp_raw > 4 ? 8 : 0);  // lanes 60..63 mirror 56..59
+    const int grp_last = grp > 3 ? 3 : grp;        // store 12 covers rows 60..63 only
+    const int lds_off = grp * L::STAGE_ROW + lane_in * 2;            // doubles
+    const unsigned g_off = (unsigned)(grp * S * 192 + lane_in * 16); // bytes
+    const int lds_off_last = grp_last * L::STAGE_ROW + lane_in * 2;
+    const unsigned g_off_last = (unsigned)(grp_last * S * 192 + lane_in * 16);
     double xn[3][3];  // free derivatives at local waypoint j+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -342,40 +357,56 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 v2.y = c[i + 1];
                 *reinterpret_cast<double2 *>(stage + lane * L::STAGE_ROW + ax * M8 + i) = v2;
             }
-            if (a.status) {
+            if (STATUS) {
 #pragma unroll
                 for (int i = 0; i < M8; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
             }
         }
-        // transposed read-back: consecutive lanes store consecutive 16-byte pieces, so one wave
-        // store covers 5.3 whole 192-byte (segment, trajectory) records instead of 64 slivers
+        // transposed read-back: 12 consecutive lanes carry the 12 16-byte pieces of one
+        // (trajectory, segment) record, 5 records per wave store.  Lane offsets are loop-invariant.
+        // LDS operations of one wave execute in order, so the staging tile needs no barrier; the
+        // fences only stop the compiler from reordering the (may-alias) LDS accesses.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * 24);  // uniform
+            if (FULL) {
+                // branch-free: lanes 60..63 (and, in the last store, the lanes whose row would be
+                // 64) repeat a neighbour's piece -- same address, same data
+                double2 v[13];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int q = i * 64 + lane;            // 16-byte piece index inside the wave's tile
-            const int row = (q * 43691) >> 19;      // q / 12 for q < 768
-            const int within = q - row * 12;
-            const double2 v2 = *reinterpret_cast<const double2 *>(stage + row * L::STAGE_ROW + within * 2);
-            if (b0 + row < a.B)
-                *reinterpret_cast<double2 *>((double *)a.coeffs + ((b0 + row) * S + g) * 24 + within * 2) = v2;
+                for (int i = 0; i < 13; ++i)
+                    v[i] = *reinterpret_cast<const double2 *>(stage + ((i < 12) ? lds_off : lds_off_last) + i * 5 * L::STAGE_ROW);
+#pragma unroll
+                for (int i = 0; i < 13; ++i)
+                    *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * S * 192 + ((i < 12) ? g_off : g_off_last)) = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    const int row = i * 5 + grp;
+                    if (lane < 60 && row < 64 && b0 + row < a.B) {
+                        const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * L::STAGE_ROW);
+                        *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * S * 192 + g_off) = v2;
+                    }
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
     }
     CSP_STAMP(4);
-    if (a.status && b0 + lane < a.B) {
+    CSP_STAMP_RT(6);
+    if (STATUS && b0 + lane < a.B) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
     }
 }
 
-template <int HS>
+// FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
+// batch is a second, single-workgroup launch of the FULL=false variant.
+template <int HS, bool STATUS, bool FULL>
 __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     using L = FixedLds<HS>;
     constexpr int S = 2 * HS;
@@ -391,6 +422,7 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
 
+    CSP_STAMP_RT(5);
     CSP_STAMP(0);
     // ---- coalesced copy-in: the workgroup's waypoints and times are contiguous in HBM ----
     {
@@ -420,8 +452,8 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
 
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
-    if (role == 0) fixed_body<HS, false>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
-    else fixed_body<HS, true>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
+    if (role == 0) fixed_body<HS, false, STATUS, FULL>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
+    else fixed_body<HS, true, STATUS, FULL>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
 }
 
 }  // namespace
@@ -451,15 +483,41 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
     // without the path penalty the reference's deviation metric is evaluated at t* = 0, where the
     // polynomial equals its waypoint exactly (minimum_snap.cpp:342, :596-617)
     if (a.max_dev && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
-    const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
-#define CSP_FIXED_CASE(hs) \
-    case 2 * hs: hipLaunchKernelGGL(minsnap_fixed_kernel<hs>, grid, block, 0, st, a); break;
+    const int64_t n_full = a.B / 64, rem = a.B % 64;
+    const dim3 block(128);
+    GenericArgs t = a;  // tail: the last B % 64 trajectories, one workgroup
+    if (rem) {
+        const int64_t off = n_full * 64;
+        t.B = rem;
+        t.wp = (const double *)a.wp + off * (a.S + 1) * 3;
+        t.times = (const double *)a.times + off * a.S;
+        t.coeffs = (double *)a.coeffs + off * a.S * 24;
+        if (a.bc_per_traj) t.bc = (const double *)a.bc + off * 12;
+        if (a.status) t.status = a.status + off;
+        if (a.vw_per) t.vw_per = a.vw_per + off;
+    }
+#define CSP_FIXED_LAUNCH(hs, st_, full_, grid_, args_) \
+    hipLaunchKernelGGL((minsnap_fixed_kernel<hs, st_, full_>), dim3((unsigned)(grid_)), block, 0, st, args_)
+#define CSP_FIXED_CASE(hs)                                                              \
+    case 2 * hs:                                                                        \
+        if (n_full) {                                                                   \
+            GenericArgs f = a;                                                          \
+            f.B = n_full * 64;                                                          \
+            if (a.status) CSP_FIXED_LAUNCH(hs, true, true, n_full, f);                  \
+            else CSP_FIXED_LAUNCH(hs, false, true, n_full, f);                          \
+        }                                                                               \
+        if (rem) {                                                                      \
+            if (a.status) CSP_FIXED_LAUNCH(hs, true, false, 1, t);                      \
+            else CSP_FIXED_LAUNCH(hs, false, false, 1, t);                              \
+        }                                                                               \
+        break;
     switch (a.S) {
         CSP_FIXED_CASE(1) CSP_FIXED_CASE(2) CSP_FIXED_CASE(3) CSP_FIXED_CASE(4)
         CSP_FIXED_CASE(5) CSP_FIXED_CASE(6) CSP_FIXED_CASE(7) CSP_FIXED_CASE(8)
         default: return hipErrorInvalidValue;
     }
 #undef CSP_FIXED_CASE
+#undef CSP_FIXED_LAUNCH
     return hipGetLastError();
 }
 

@@ -28,13 +28,21 @@ torch.cuda.synchronize()
 n = 4096 * 8
 buf = (ctypes.c_ulonglong * n)()
 lib.csp_debug_read_stamps(buf, n)
-st = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:4096, :5].astype(np.int64)
+raw = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)[:4096].astype(np.int64)
+raw = raw[(raw[:, 0] > 0) & (raw[:, 4] > 0)]        # rows a wave actually wrote
+st = raw[:, :5]
+rt0, rt1 = raw[:, 5], raw[:, 6]
 d = np.diff(st, axis=1)
-names = ["copy-in+barrier", "forward sweep", "carry+exchange barrier", "mid solve+backward+stores"]
+names = ["copy-in + barrier", "(stamp slack)", "forward sweep + carry + exchange barrier", "mid solve + backward + stores"]
 tot = (st[:, 4] - st[:, 0])
-print("waves sampled:", len(st), " median wave lifetime (s_memtime ticks):", int(np.median(tot)))
+print("waves sampled:", len(st), " median wave lifetime (shader cycles):", int(np.median(tot)))
 for i, nme in enumerate(names):
-    print("  %-28s median %8d  mean %8d  share %.1f%%" % (nme, np.median(d[:, i]), d[:, i].mean(), 100 * d[:, i].sum() / tot.sum()))
-t0 = st[:, 0] - st[:, 0].min()
-print("kernel span (ticks):", int(st[:, 4].max() - st[:, 0].min()), " start-time spread p50/p90/max:", int(np.median(t0)), int(np.percentile(t0, 90)), int(t0.max()))
-print("top role lifetime median", int(np.median(tot[0::2])), " bottom", int(np.median(tot[1::2])))
+    print("  %-42s median %8d  share %.1f%%" % (nme, np.median(d[:, i]), 100 * d[:, i].sum() / tot.sum()))
+span = rt1.max() - rt0.min()
+print("kernel span: %.1f us (s_memrealtime, 100 MHz)" % (span / 100.0))
+life = (rt1 - rt0) / 100.0
+print("wave lifetime us: median %.2f p10 %.2f p90 %.2f ; shader clock %.2f GHz" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90), np.median(tot) / np.median(life) / 1000.0))
+start = (rt0 - rt0.min()) / 100.0
+hist, edges = np.histogram(start, bins=12, range=(0, span / 100.0))
+print("wave start-time histogram (us):", [(round(float(e), 1), int(h)) for e, h in zip(edges[:-1], hist)])
+print("average resident waves over the span: %.0f of 1024 SIMD slots" % (life.sum() / (span / 100.0)))
