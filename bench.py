@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--segment-major", action="store_true",
+                    help="experiment: CSP_FLAG_SEGMENT_MAJOR coefficient layout [S][B][3][2o]")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time the CSP_MEM_HOST boundary (PCIe-inclusive; reported as a side note, never `value`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,7 +93,8 @@ def main():
     kernel = csp.kernel_name(desc)
 
     def step():
-        csp.solve_batch(d_wp, d_tm, d_bc, order=o, out=out, workspace=ws, force_generic=args.force_generic)
+        csp.solve_batch(d_wp, d_tm, d_bc, order=o, out=out, workspace=ws, force_generic=args.force_generic,
+                        segment_major=args.segment_major)
 
     def fence():
         if world > 1:
@@ -135,17 +140,26 @@ def main():
             "config": {"workload": "C3: B=%d trajectories/GPU x %d segments, order %d (degree %d), "
                                    "3 axes, fp64, zero boundary vel/acc, penalties off" % (B, S, o, 2 * o - 1),
                        "batch_per_gpu": B, "segments": S, "order": o, "kernel": kernel,
+                       "coeff_layout": "[S][B][3][2o] (CSP_FLAG_SEGMENT_MAJOR)" if args.segment_major else "[B][S][3][2o]",
                        "sharding": "independent trajectories per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_solve": bytes_per_solve, "kernel": kernel,
                          "kernel_ms": kernel_ms},
         }
+        if args.host_path and world == 1:
+            csp.solve_batch(wp, tm, order=o, force_generic=args.force_generic)
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                csp.solve_batch(wp, tm, order=o, force_generic=args.force_generic)
+            res["host_path_solves_per_s"] = B * reps / (time.perf_counter() - t1)
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, n = cpu_baseline(o, S, wp, tm, args.cpu_budget)
             res["cpu_baseline"] = cb
             chk = min(n, 1024)
-            res["parity_max_rel_err"] = synth.rel_err(out[:chk].cpu().numpy(), ref[:chk])
+            got = out.view(S, B, 3, 2 * o).permute(1, 0, 2, 3)[:chk] if args.segment_major else out[:chk]
+            res["parity_max_rel_err"] = synth.rel_err(got.cpu().numpy(), ref[:chk])
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -31,6 +31,7 @@ ABI_VERSION = 1
 DTYPE_F64, DTYPE_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_FORCE_GENERIC = 0x1
+FLAG_SEGMENT_MAJOR = 0x2
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
@@ -153,7 +154,7 @@ class Result:
 def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
                 seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
                 want_max_dev=False, want_status=False, out=None, workspace=None, stream=None,
-                force_generic=False):
+                force_generic=False, segment_major=False):
     """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
 
     numpy inputs  -> CSP_MEM_HOST (staged through the device, synchronous);
@@ -166,7 +167,9 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     """
     on_device = _is_torch(waypoints)
     ragged = seg_offsets is not None
-    flags = FLAG_FORCE_GENERIC if force_generic else 0
+    flags = (FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
+    if segment_major and ragged:
+        raise ValueError("segment_major needs a uniform batch")
     m = 2 * int(order)
     if on_device:
         import torch
@@ -193,7 +196,7 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
             raise ValueError("bc must be [4,3], [1,4,3] or [B,4,3]")
         per = bc.shape[0] == B
         if out is None:
-            out = torch.empty((total, 3, m) if ragged else (B, S, 3, m), dtype=tdt, device=dev)
+            out = torch.empty((total, 3, m) if ragged else ((S, B, 3, m) if segment_major else (B, S, 3, m)), dtype=tdt, device=dev)
         md = torch.empty(B, dtype=torch.float64, device=dev) if want_max_dev else None
         stt = torch.empty(B, dtype=torch.int32, device=dev) if want_status else None
         vwp = None
@@ -235,7 +238,7 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
         raise ValueError("bc must be [4,3], [1,4,3] or [B,4,3]")
     per = bc.shape[0] == B
     if out is None:
-        out = np.empty((total, 3, m) if ragged else (B, S, 3, m), dtype=npdt)
+        out = np.empty((total, 3, m) if ragged else ((S, B, 3, m) if segment_major else (B, S, 3, m)), dtype=npdt)
     md = np.empty(B, dtype=np.float64) if want_max_dev else None
     stt = np.empty(B, dtype=np.int32) if want_status else None
     vwp = None

@@ -43,6 +43,7 @@ int validate(const csp_minsnap_desc *d, Shape &s) {
     if (d->order > 5) return CSP_ERR_UNSUPPORTED;
     if (d->batch < 0 || d->num_segments < 0) return CSP_ERR_INVALID_ARG;
     if (d->path_weight < 0.0 || d->vel_zero_weight < 0.0) return CSP_ERR_INVALID_ARG;
+    if ((d->flags & CSP_FLAG_SEGMENT_MAJOR) && d->num_segments == 0) return CSP_ERR_INVALID_ARG;
     s.f32 = d->dtype == CSP_DTYPE_F32;
     s.elt = s.f32 ? 4 : 8;
     s.order = d->order;
@@ -109,6 +110,9 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.path_weight = d->path_weight;
     a.vel_zero_weight = d->vel_zero_weight;
     a.B = s.B; a.S = s.S; a.order = s.order; a.bc_per_traj = d->bc_per_trajectory ? 1 : 0;
+    a.seg_major = (d->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
+    a.Btotal = s.B;
+    a.Boffset = 0;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;

@@ -142,7 +142,7 @@ template <int HS> struct FixedLds {
     static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES + XCH_DOUBLES;
 };
 
-template <int HS, bool BOTTOM, bool STATUS, bool FULL>
+template <int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
                                            const double *l_wp, const double *l_tm, double *stage,
                                            double (*xch)[15][64]) {
@@ -299,9 +299,12 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     const int lane_in = lane - grp_raw * 12 + (grp_raw > 4 ? 8 : 0);  // lanes 60..63 mirror 56..59
     const int grp_last = grp > 3 ? 3 : grp;        // store 12 covers rows 60..63 only
     const int lds_off = grp * L::STAGE_ROW + lane_in * 2;            // doubles
-    const unsigned g_off = (unsigned)(grp * S * 192 + lane_in * 16); // bytes
+    // bytes between consecutive trajectories' records of one segment: the default layout is
+    // [B][S][3][8] (3072-byte stride at S=16); CSP_FLAG_SEGMENT_MAJOR selects [S][B][3][8]
+    constexpr int RS = SEGMAJ ? 192 : S * 192;
+    const unsigned g_off = (unsigned)(grp * RS + lane_in * 16); // bytes
     const int lds_off_last = grp_last * L::STAGE_ROW + lane_in * 2;
-    const unsigned g_off_last = (unsigned)(grp_last * S * 192 + lane_in * 16);
+    const unsigned g_off_last = (unsigned)(grp_last * RS + lane_in * 16);
     double xn[3][3];  // free derivatives at local waypoint j+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -368,7 +371,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         // fences only stop the compiler from reordering the (may-alias) LDS accesses.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         {
-            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * 24);  // uniform
+            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (SEGMAJ ? ((int64_t)g * a.Btotal + a.Boffset + b0) : (b0 * S + g)) * 24);  // uniform
             if (FULL) {
                 // branch-free: lanes 60..63 (and, in the last store, the lanes whose row would be
                 // 64) repeat a neighbour's piece -- same address, same data
@@ -378,14 +381,14 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                     v[i] = *reinterpret_cast<const double2 *>(stage + ((i < 12) ? lds_off : lds_off_last) + i * 5 * L::STAGE_ROW);
 #pragma unroll
                 for (int i = 0; i < 13; ++i)
-                    *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * S * 192 + ((i < 12) ? g_off : g_off_last)) = v[i];
+                    *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + ((i < 12) ? g_off : g_off_last)) = v[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
                     const int row = i * 5 + grp;
                     if (lane < 60 && row < 64 && b0 + row < a.B) {
                         const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * L::STAGE_ROW);
-                        *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * S * 192 + g_off) = v2;
+                        *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + g_off) = v2;
                     }
                 }
             }
@@ -406,7 +409,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
 // FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
 // batch is a second, single-workgroup launch of the FULL=false variant.
-template <int HS, bool STATUS, bool FULL>
+template <int HS, bool STATUS, bool FULL, bool SEGMAJ>
 __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     using L = FixedLds<HS>;
     constexpr int S = 2 * HS;
@@ -452,8 +455,8 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
 
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
-    if (role == 0) fixed_body<HS, false, STATUS, FULL>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
-    else fixed_body<HS, true, STATUS, FULL>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
+    if (role == 0) fixed_body<HS, false, STATUS, FULL, SEGMAJ>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
+    else fixed_body<HS, true, STATUS, FULL, SEGMAJ>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
 }
 
 }  // namespace
@@ -491,13 +494,19 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
         t.B = rem;
         t.wp = (const double *)a.wp + off * (a.S + 1) * 3;
         t.times = (const double *)a.times + off * a.S;
-        t.coeffs = (double *)a.coeffs + off * a.S * 24;
+        if (a.seg_major) t.Boffset = off;   // segment-major records are addressed from the batch start
+        else t.coeffs = (double *)a.coeffs + off * a.S * 24;
         if (a.bc_per_traj) t.bc = (const double *)a.bc + off * 12;
         if (a.status) t.status = a.status + off;
         if (a.vw_per) t.vw_per = a.vw_per + off;
     }
-#define CSP_FIXED_LAUNCH(hs, st_, full_, grid_, args_) \
-    hipLaunchKernelGGL((minsnap_fixed_kernel<hs, st_, full_>), dim3((unsigned)(grid_)), block, 0, st, args_)
+#define CSP_FIXED_LAUNCH(hs, st_, full_, grid_, args_)                                                          \
+    do {                                                                                                        \
+        if (a.seg_major)                                                                                        \
+            hipLaunchKernelGGL((minsnap_fixed_kernel<hs, st_, full_, true>), dim3((unsigned)(grid_)), block, 0, st, args_);  \
+        else                                                                                                    \
+            hipLaunchKernelGGL((minsnap_fixed_kernel<hs, st_, full_, false>), dim3((unsigned)(grid_)), block, 0, st, args_); \
+    } while (0)
 #define CSP_FIXED_CASE(hs)                                                              \
     case 2 * hs:                                                                        \
         if (n_full) {                                                                   \

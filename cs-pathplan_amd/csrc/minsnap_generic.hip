@@ -18,7 +18,8 @@ __device__ __forceinline__ void load3(const R *p, R (&v)[3]) { v[0] = p[0]; v[1]
 template <int O, typename R> struct TrajView {
     const R *wp;     // [(S+1)][3]
     const R *tm;     // [S]
-    R *co;           // [S][3][2O]
+    R *co;           // segment k's record at co + k*seg_stride: [3][2O]
+    int64_t seg_stride;  // 3*2O (trajectory-major) or B*3*2O (CSP_FLAG_SEGMENT_MAJOR)
     int S;
 };
 
@@ -142,7 +143,7 @@ __device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1
 #pragma unroll
             for (int r = 0; r < N; ++r) { d[r + 1] = xk[r][ax]; d[O + r + 1] = xn[r][ax]; }
             recover_axis<O, R>(d, tp, ip, c);
-            R *dst = tv.co + ((int64_t)k * 3 + ax) * M;
+            R *dst = tv.co + (int64_t)k * tv.seg_stride + ax * M;
 #pragma unroll
             for (int i = 0; i < M; ++i) { dst[i] = c[i]; nanacc = fma_<R>(c[i], R(0), nanacc); }
             if (dev_out) {
@@ -186,7 +187,7 @@ __device__ void pick_tstar(const TrajView<O, R> &tv, int *tstar, int64_t B) {
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
-            for (int i = 0; i < M; ++i) c[ax][i] = tv.co[((int64_t)k * 3 + ax) * M + i];
+            for (int i = 0; i < M; ++i) c[ax][i] = tv.co[(int64_t)k * tv.seg_stride + ax * M + i];
         int best = 0;
         R bestd = R(-1);
         for (int s = 0; s <= 16; ++s) {
@@ -221,7 +222,8 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     TrajView<O, R> tv;
     tv.wp = (const R *)a.wp + (seg0 + b) * 3;
     tv.tm = (const R *)a.times + seg0;
-    tv.co = (R *)a.coeffs + seg0 * 3 * M;
+    if (a.seg_major && !a.seg_off) { tv.co = (R *)a.coeffs + b * 3 * M; tv.seg_stride = a.B * 3 * M; }
+    else { tv.co = (R *)a.coeffs + seg0 * 3 * M; tv.seg_stride = 3 * M; }
     tv.S = S;
     const R *bc = (const R *)a.bc + (a.bc_per_traj ? b * 12 : 0);
     // fixed boundary derivatives (minimum_snap.cpp:527-555): velocity if order>=2,

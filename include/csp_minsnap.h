@@ -58,6 +58,10 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 
 /* flags */
 #define CSP_FLAG_FORCE_GENERIC 0x1u /* never dispatch the register-resident fixed-size kernel */
+#define CSP_FLAG_SEGMENT_MAJOR 0x2u /* uniform batches only: coeffs laid out [S][B][3][2*order]
+                                       (segment-major) instead of [B][S][3][2*order]; each
+                                       (segment, trajectory) record keeps the reference's row
+                                       content (3*p_num1d values, highest power first) */
 
 /* per-trajectory status bits written to `status` */
 #define CSP_TRAJ_OK 0

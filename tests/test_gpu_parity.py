@@ -89,6 +89,17 @@ def test_device_memory_path_matches_host_path(csp):
     assert np.array_equal(host.coeffs, dev.coeffs.cpu().numpy())
 
 
+@pytest.mark.parametrize("B", [64, 200, 1])
+def test_segment_major_layout(csp, B):
+    """CSP_FLAG_SEGMENT_MAJOR is a pure permutation of the default layout (both kernels, ragged tail)."""
+    wp, tm = synth.make_batch(B, 16, config_id=3)
+    for force in (False, True):
+        a = csp.solve_batch(wp, tm, order=4, force_generic=force).coeffs
+        b = csp.solve_batch(wp, tm, order=4, force_generic=force, segment_major=True).coeffs
+        assert b.shape == (16, B, 3, 8)
+        assert np.array_equal(np.transpose(b, (1, 0, 2, 3)), a)
+
+
 def test_ragged_batch(csp, oracle_mod):
     trajs = [t for t in synth.make_ragged(96, smin=1, smax=40) if t[0] == 4]
     wp = np.concatenate([t[1] for t in trajs])
