@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--segment-major", action="store_true",
                     help="experiment: CSP_FLAG_SEGMENT_MAJOR coefficient layout [S][B][3][2o]")
+    ap.add_argument("--no-persistent", action="store_true", help="A/B: CSP_FLAG_NO_PERSISTENT")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the CSP_MEM_HOST boundary (PCIe-inclusive; reported as a side note, never `value`)")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
 
     def step():
         csp.solve_batch(d_wp, d_tm, d_bc, order=o, out=out, workspace=ws, force_generic=args.force_generic,
-                        segment_major=args.segment_major)
+                        segment_major=args.segment_major, no_persistent=args.no_persistent)
 
     def fence():
         if world > 1:

@@ -32,6 +32,7 @@ DTYPE_F64, DTYPE_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_FORCE_GENERIC = 0x1
 FLAG_SEGMENT_MAJOR = 0x2
+FLAG_NO_PERSISTENT = 0x4
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
@@ -154,7 +155,7 @@ class Result:
 def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
                 seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
                 want_max_dev=False, want_status=False, out=None, workspace=None, stream=None,
-                force_generic=False, segment_major=False):
+                force_generic=False, segment_major=False, no_persistent=False):
     """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
 
     numpy inputs  -> CSP_MEM_HOST (staged through the device, synchronous);
@@ -167,7 +168,8 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     """
     on_device = _is_torch(waypoints)
     ragged = seg_offsets is not None
-    flags = (FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
+    flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
+             | (FLAG_NO_PERSISTENT if no_persistent else 0))
     if segment_major and ragged:
         raise ValueError("segment_major needs a uniform batch")
     m = 2 * int(order)

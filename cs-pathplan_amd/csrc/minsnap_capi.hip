@@ -113,6 +113,7 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.seg_major = (d->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
     a.Btotal = s.B;
     a.Boffset = 0;
+    a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;

@@ -16,6 +16,8 @@
 #include "minsnap_device.h"
 #include "minsnap_launch.h"
 
+#include <type_traits>
+
 #ifdef CSP_STAMPS
 // Diagnostic build only (python cs-pathplan_amd/build.py --stamps): per-wave s_memtime stamps
 // written to a buffer nothing else reads.  The shipped library contains none of this.
@@ -53,6 +55,13 @@ constexpr int M8 = 8;
 // Scaled per-segment constants for order 4 (free derivatives r = 1..3 -> index r-1).
 // ee[r][c] = (-1)^(r+c) ss[r][c] and Qt[.][end pos] = -Qt[.][start pos] (checked in
 // tests/test_tables.py), so only ss, se and the two position columns are formed.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for every
+// outstanding global store (vmcnt(0)); the persistent kernel keeps stores and the next
+// workgroup's LDS-DMA in flight across its barriers.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct Seg4 {
     double ss[3][3];  // symmetric; full storage keeps the unrolled code simple
     double se[3][3];
@@ -142,18 +151,34 @@ template <int HS> struct FixedLds {
     static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES + XCH_DOUBLES;
 };
 
-template <int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// Input accessors: local (role-oriented) segment times T(j), j = 0..HS-1, and waypoints P(j, axis),
+// j = 0..HS.  The bottom role walks its half of the trajectory backwards.
+template <int HS, bool BOTTOM, int TM_STRIDE = FixedLds<HS>::TM_ROW> struct LdsInputs {   // read on demand from the workgroup's LDS image
+    const double *l_wp, *l_tm;
+    int lane;
+    __device__ __forceinline__ double T(int j) const { return l_tm[lane * TM_STRIDE + (BOTTOM ? 2 * HS - 1 - j : j)]; }
+    __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * FixedLds<HS>::WP_ROW + (BOTTOM ? 2 * HS - j : j) * 3 + ax]; }
+};
+template <int HS> struct RegInputs {                // pulled into registers once per trajectory
+    double t[HS], p[HS + 1][3];
+    __device__ __forceinline__ double T(int j) const { return t[j]; }
+    __device__ __forceinline__ double P(int j, int ax) const { return p[j][ax]; }
+};
+
+// STASH: the forward sweep keeps the times/waypoints it reads in registers for the backward sweep,
+// so the LDS input image is dead after the exchange barrier; `after_exchange()` runs right after
+// that barrier (the persistent kernel issues the next slice's LDS-DMA there).
+template <int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
-                                           const double *l_wp, const double *l_tm, double *stage,
-                                           double (*xch)[15][64]) {
+                                           const In &in, double *stage, double (*xch)[15][64],
+                                           const Hook &after_exchange) {
     constexpr int S = 2 * HS;
     using L = FixedLds<HS>;
     const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
-
-    // ---- local (role-oriented) inputs come from the LDS image of the workgroup's 64 trajectories;
-    // the bottom role walks its half backwards ----
-    auto Tl = [&](int j) { return l_tm[lane * L::TM_ROW + (BOTTOM ? S - 1 - j : j)]; };
-    auto Pl = [&](int j, int ax) { return l_wp[lane * L::WP_ROW + (BOTTOM ? S - j : j) * 3 + ax]; };
+    auto Tl = [&](int j) { return in.T(j); };
+    auto Pl = [&](int j, int ax) { return in.P(j, ax); };
     const double vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
 
     // boundary derivatives (minimum_snap.cpp:527-555): vel, acc given, jerk pinned to 0;
@@ -174,15 +199,20 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
     // ---- forward elimination over local interior waypoints 1..HS-1 ----
     Seg4 left, right;
-    seg4(Tl(0), vw, left);
+    double Tst[HS], Pst[HS + 1][3];  // STASH only
+    { const double t0 = Tl(0); if (STASH) Tst[0] = t0; seg4(t0, vw, left); }
     double Pa[3], Pb[3], Pc[3];  // local waypoints k-1, k, k+1
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pl(0, ax); Pb[ax] = Pl(1, ax); }
+    for (int ax = 0; ax < 3; ++ax) {
+        Pa[ax] = Pl(0, ax);
+        Pb[ax] = Pl(1, ax);
+        if (STASH) { Pst[0][ax] = Pa[ax]; Pst[1][ax] = Pb[ax]; }
+    }
 #pragma unroll
     for (int k = 1; k < HS; ++k) {
-        seg4(Tl(k), vw, right);
+        { const double tk = Tl(k); if (STASH) Tst[k] = tk; seg4(tk, vw, right); }
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) Pc[ax] = Pl(k + 1, ax);
+        for (int ax = 0; ax < 3; ++ax) { Pc[ax] = Pl(k + 1, ax); if (STASH) Pst[k + 1][ax] = Pc[ax]; }
         double Sm[3][3], y[3][3], I[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -259,7 +289,8 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) mine[e++][lane] = cm[r][ax];
     }
-    __syncthreads();
+    lds_barrier();
+    after_exchange();
     CSP_STAMP(3);
     double xm[3][3];
     {
@@ -328,7 +359,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                     xk[r][ax] = v;
                 }
             }
-        const double Tj = Tl(j);
+        const double Tj = STASH ? Tst[j] : Tl(j);
         double ip[M8], tp[3];
         ip[0] = 1.0;
         ip[1] = fast_rcp(Tj);
@@ -349,8 +380,9 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 xs[r] = BOTTOM ? sgn * xn[r][ax] : xk[r][ax];
                 xe[r] = BOTTOM ? sgn * xk[r][ax] : xn[r][ax];
             }
-            const double Ps = BOTTOM ? Pl(j + 1, ax) : Pl(j, ax);
-            const double Pe = BOTTOM ? Pl(j, ax) : Pl(j + 1, ax);
+            const double Plo = STASH ? Pst[j][ax] : Pl(j, ax), Phi = STASH ? Pst[j + 1][ax] : Pl(j + 1, ax);
+            const double Ps = BOTTOM ? Phi : Plo;
+            const double Pe = BOTTOM ? Plo : Phi;
             recover4(Ps, Pe - Ps, xs, xe, tp, ip, c);
             // lane-major staging tile: row = lane, 208-byte rows keep ds_write_b128 conflict-free
 #pragma unroll
@@ -455,8 +487,102 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
 
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
-    if (role == 0) fixed_body<HS, false, STATUS, FULL, SEGMAJ>(a, b0, b, lane, l_wp, l_tm, l_stage, xch);
-    else fixed_body<HS, true, STATUS, FULL, SEGMAJ>(a, b0, b, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch);
+    if (role == 0) {
+        const LdsInputs<HS, false> in{l_wp, l_tm, lane};
+        fixed_body<HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage, xch, NoHook{});
+    } else {
+        const LdsInputs<HS, true> in{l_wp, l_tm, lane};
+        fixed_body<HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage + L::STAGE_DOUBLES, xch, NoHook{});
+    }
+}
+
+// LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no registers in between) of one 64-trajectory
+// slice: waypoints then times, copied linearly in 16-byte pieces, 1 KiB per wave instruction.
+template <int HS> struct SlicePrefetch {
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    typedef __attribute__((address_space(3))) char *lchar_t;
+    using L = FixedLds<HS>;
+    static constexpr int S = 2 * HS;
+    static constexpr int WP_PIECES = 64 * L::WP_ROW / 2;   // 64*WP_ROW is even
+    static constexpr int TM_PIECES = 64 * S / 2;
+    static constexpr int WP_ITERS = (WP_PIECES + 127) / 128, TM_ITERS = (TM_PIECES + 127) / 128;
+    static constexpr int TM_BYTE_OFF = 64 * L::WP_ROW * 8;
+    const char *wp, *tm;     // batch base pointers
+    lchar_t lds3;            // LDS image base (waypoints, then unpadded times)
+    int tid, role;
+    int64_t next, n_slices;
+    __device__ __forceinline__ void issue(int64_t slice) const {
+        const char *g_wp = wp + slice * (64 * L::WP_ROW * 8);
+        const char *g_tm = tm + slice * (64 * S * 8);
+#pragma unroll
+        for (int it = 0; it < WP_ITERS; ++it) {
+            const int q = it * 128 + tid;  // piece index; a wave's 64 pieces are contiguous
+            if (q < WP_PIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g_wp + (size_t)q * 16), (lptr_t)(lds3 + (it * 128 + role * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < TM_ITERS; ++it) {
+            const int q = it * 128 + tid;
+            if (q < TM_PIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g_tm + (size_t)q * 16), (lptr_t)(lds3 + TM_BYTE_OFF + (it * 128 + role * 64) * 16), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void operator()() const { if (next < n_slices) issue(next); }
+};
+
+template <int HS, bool BOTTOM, bool STATUS, bool SEGMAJ>
+__device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n_slices, int lane, const double *l_wp,
+                                                     const double *l_tm, double *stage, double (*xch)[15][64],
+                                                     SlicePrefetch<HS> pf) {
+    constexpr int S = 2 * HS;
+    constexpr int STORES_PER_SLICE = 13 * HS;  // per wave; all younger than that slice's prefetch
+    bool first = true;
+    for (int64_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        // the prefetch of this slice is older than every store of the previous slice, so waiting for
+        // all but the youngest min(63, stores) operations covers it without draining the stores
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES_PER_SLICE < 63 ? STORES_PER_SLICE : 63) : "memory");
+        lds_barrier();
+        if (first) CSP_STAMP(1);
+        const LdsInputs<HS, BOTTOM, S> in{l_wp, l_tm, lane};  // unpadded rows: LDS-DMA writes linearly
+        const int64_t b0 = slice * 64;
+        pf.next = slice + gridDim.x;
+        // the image is dead once both waves passed the exchange barrier: prefetch the next slice there
+        fixed_body<HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, stage, xch, pf);
+        first = false;
+    }
+}
+
+// Persistent variant for the full workgroups of a batch: gridDim.x workgroups (two per CU) walk the
+// batch with stride gridDim.x; the NEXT slice's inputs stream into LDS while the current slice is
+// back-substituted and stored, so only a workgroup's very first copy-in is exposed.
+template <int HS, bool STATUS, bool SEGMAJ>
+__global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericArgs a, int n_slices) {
+    using L = FixedLds<HS>;
+    constexpr int S = 2 * HS;
+    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES + L::XCH_DOUBLES];
+    double *l_wp = lds;
+    double *l_tm = l_wp + 64 * L::WP_ROW;
+    double *l_stage = l_tm + 64 * S;
+    double(*xch)[15][64] = reinterpret_cast<double(*)[15][64]>(l_stage + 2 * L::STAGE_DOUBLES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int role = tid >> 6;  // wave-uniform
+    SlicePrefetch<HS> pf;
+    pf.wp = reinterpret_cast<const char *>(a.wp);
+    pf.tm = reinterpret_cast<const char *>(a.times);
+    pf.lds3 = (typename SlicePrefetch<HS>::lchar_t)lds;  // cast straight from the LDS object
+    pf.tid = tid;
+    pf.role = role;
+    pf.next = 0;
+    pf.n_slices = n_slices;
+    CSP_STAMP_RT(5);
+    CSP_STAMP(0);
+    if ((int64_t)blockIdx.x < n_slices) pf.issue(blockIdx.x);
+    // one loop per role: each wave's instruction stream holds a single specialisation
+    if (role == 0) persistent_role_loop<HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, xch, pf);
+    else persistent_role_loop<HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch, pf);
 }
 
 }  // namespace
@@ -488,6 +614,15 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
     if (a.max_dev && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
     const int64_t n_full = a.B / 64, rem = a.B % 64;
     const dim3 block(128);
+    // persistent grid: two workgroups per CU (register- and LDS-limited residency of this kernel)
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int64_t pgrid = n_full < 2 * (int64_t)cus ? n_full : 2 * (int64_t)cus;
     GenericArgs t = a;  // tail: the last B % 64 trajectories, one workgroup
     if (rem) {
         const int64_t off = n_full * 64;
@@ -500,6 +635,13 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
         if (a.status) t.status = a.status + off;
         if (a.vw_per) t.vw_per = a.vw_per + off;
     }
+#define CSP_FIXED_PERSIST(hs, st_, args_)                                                                       \
+    do {                                                                                                        \
+        if (a.seg_major)                                                                                        \
+            hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<hs, st_, true>), dim3((unsigned)pgrid), block, 0, st, args_, (int)n_full);  \
+        else                                                                                                    \
+            hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<hs, st_, false>), dim3((unsigned)pgrid), block, 0, st, args_, (int)n_full); \
+    } while (0)
 #define CSP_FIXED_LAUNCH(hs, st_, full_, grid_, args_)                                                          \
     do {                                                                                                        \
         if (a.seg_major)                                                                                        \
@@ -512,7 +654,10 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
         if (n_full) {                                                                   \
             GenericArgs f = a;                                                          \
             f.B = n_full * 64;                                                          \
-            if (a.status) CSP_FIXED_LAUNCH(hs, true, true, n_full, f);                  \
+            if (a.persistent) {                                                         \
+                if (a.status) CSP_FIXED_PERSIST(hs, true, f);                           \
+                else CSP_FIXED_PERSIST(hs, false, f);                                   \
+            } else if (a.status) CSP_FIXED_LAUNCH(hs, true, true, n_full, f);           \
             else CSP_FIXED_LAUNCH(hs, false, true, n_full, f);                          \
         }                                                                               \
         if (rem) {                                                                      \
@@ -527,6 +672,7 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
     }
 #undef CSP_FIXED_CASE
 #undef CSP_FIXED_LAUNCH
+#undef CSP_FIXED_PERSIST
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct GenericArgs {
     int seg_major;          // coeffs laid out [S][B][3][2o] instead of [B][S][3][2o] (uniform S only)
     int64_t Btotal;         // seg_major: the batch size the layout is indexed by
     int64_t Boffset;        // seg_major: first trajectory of this launch inside that batch
+    int persistent;         // fixed kernel: persistent workgroups with LDS-DMA prefetch (default on)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, hipStream_t st);

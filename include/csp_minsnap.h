@@ -63,6 +63,9 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
                                        (segment, trajectory) record keeps the reference's row
                                        content (3*p_num1d values, highest power first) */
 
+#define CSP_FLAG_NO_PERSISTENT 0x4u  /* fixed kernel: one workgroup per 64 trajectories instead of
+                                       persistent workgroups with LDS-DMA prefetch (A/B testing) */
+
 /* per-trajectory status bits written to `status` */
 #define CSP_TRAJ_OK 0
 #define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently) */
