@@ -325,17 +325,13 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
     // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
     double nanacc = 0.0;
-    const int grp_raw = (lane * 43691) >> 19;      // lane / 12 (5 for lanes 60..63)
-    const int grp = grp_raw > 4 ? 4 : grp_raw;
-    const int lane_in = lane - grp_raw * 12 + (grp_raw > 4 ? 8 : 0);  // lanes 60..63 mirror 56..59
-    const int grp_last = grp > 3 ? 3 : grp;        // store 12 covers rows 60..63 only
+    const int grp = (lane * 43691) >> 19;          // lane / 12 (5 for the idle lanes 60..63)
+    const int lane_in = lane - grp * 12;
     const int lds_off = grp * L::STAGE_ROW + lane_in * 2;            // doubles
     // bytes between consecutive trajectories' records of one segment: the default layout is
     // [B][S][3][8] (3072-byte stride at S=16); CSP_FLAG_SEGMENT_MAJOR selects [S][B][3][8]
     constexpr int RS = SEGMAJ ? 192 : S * 192;
     const unsigned g_off = (unsigned)(grp * RS + lane_in * 16); // bytes
-    const int lds_off_last = grp_last * L::STAGE_ROW + lane_in * 2;
-    const unsigned g_off_last = (unsigned)(grp_last * RS + lane_in * 16);
     double xn[3][3];  // free derivatives at local waypoint j+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -405,15 +401,21 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         {
             char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (SEGMAJ ? ((int64_t)g * a.Btotal + a.Boffset + b0) : (b0 * S + g)) * 24);  // uniform
             if (FULL) {
-                // branch-free: lanes 60..63 (and, in the last store, the lanes whose row would be
-                // 64) repeat a neighbour's piece -- same address, same data
-                double2 v[13];
+                // 12 stores by lanes 0..59 (rows 0..59), a 13th by lanes 0..47 (rows 60..63); idle
+                // lanes are masked off rather than made to repeat a neighbour's piece -- duplicate
+                // stores are real write traffic (they showed up as +6 % WRITE_SIZE)
+                if (lane < 60) {
+                    double2 v[12];
 #pragma unroll
-                for (int i = 0; i < 13; ++i)
-                    v[i] = *reinterpret_cast<const double2 *>(stage + ((i < 12) ? lds_off : lds_off_last) + i * 5 * L::STAGE_ROW);
+                    for (int i = 0; i < 12; ++i)
+                        v[i] = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * L::STAGE_ROW);
 #pragma unroll
-                for (int i = 0; i < 13; ++i)
-                    *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + ((i < 12) ? g_off : g_off_last)) = v[i];
+                    for (int i = 0; i < 12; ++i)
+                        *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + g_off) = v[i];
+                    if (lane < 48)
+                        *reinterpret_cast<double2 *>(gbase + (size_t)12 * 5 * RS + g_off) =
+                            *reinterpret_cast<const double2 *>(stage + lds_off + 12 * 5 * L::STAGE_ROW);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
