@@ -33,6 +33,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_FORCE_GENERIC = 0x1
 FLAG_SEGMENT_MAJOR = 0x2
 FLAG_NO_PERSISTENT = 0x4
+FLAG_F32_ARITH = 0x8
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
@@ -155,7 +156,7 @@ class Result:
 def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
                 seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
                 want_max_dev=False, want_status=False, out=None, workspace=None, stream=None,
-                force_generic=False, segment_major=False, no_persistent=False):
+                force_generic=False, segment_major=False, no_persistent=False, f32_arith=False):
     """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
 
     numpy inputs  -> CSP_MEM_HOST (staged through the device, synchronous);
@@ -169,7 +170,7 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     on_device = _is_torch(waypoints)
     ragged = seg_offsets is not None
     flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
-             | (FLAG_NO_PERSISTENT if no_persistent else 0))
+             | (FLAG_NO_PERSISTENT if no_persistent else 0) | (FLAG_F32_ARITH if f32_arith else 0))
     if segment_major and ragged:
         raise ValueError("segment_major needs a uniform batch")
     m = 2 * int(order)

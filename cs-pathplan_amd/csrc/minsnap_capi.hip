@@ -66,8 +66,9 @@ bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
 
 size_t ws_bytes(const csp_minsnap_desc *d, const Shape &s, size_t *tstar_off) {
     if (use_fixed(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
+    const size_t ws_elt = (s.f32 && (d->flags & CSP_FLAG_F32_ARITH)) ? 4 : 8;  // workspace holds the arithmetic type
     size_t factors = align_up((size_t)(s.Smax > 1 ? s.Smax - 1 : 0) * csp::generic_ws_entries(s.order) *
-                                  (size_t)s.B * s.elt, 256);
+                                  (size_t)s.B * ws_elt, 256);
     if (tstar_off) *tstar_off = factors;
     size_t ts = d->path_weight > 0.0 ? align_up((size_t)s.Smax * (size_t)s.B * sizeof(int), 256) : 0;
     return factors + ts;
@@ -114,7 +115,7 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.Btotal = s.B;
     a.Boffset = 0;
     a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
-    hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, st);
+    hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;
 }
@@ -160,7 +161,8 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
     Shape s;
     if (validate(desc, s) != CSP_OK) return nullptr;
     if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.S);
-    std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order, s.f32 ? "f32" : "f64", s.ragged ? "_ragged" : "");
+    std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order,
+                  !s.f32 ? "f64" : ((desc->flags & CSP_FLAG_F32_ARITH) ? "f32" : "f32io_f64"), s.ragged ? "_ragged" : "");
     return name;
 }
 

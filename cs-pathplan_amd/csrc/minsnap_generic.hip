@@ -12,21 +12,22 @@
 
 namespace csp {
 
-template <int O, typename R>
-__device__ __forceinline__ void load3(const R *p, R (&v)[3]) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; }
+// IO = storage type of waypoints/times/bc/coeffs, R = arithmetic (and workspace) type.
+template <typename IO, typename R>
+__device__ __forceinline__ void load3(const IO *p, R (&v)[3]) { v[0] = R(p[0]); v[1] = R(p[1]); v[2] = R(p[2]); }
 
-template <int O, typename R> struct TrajView {
-    const R *wp;     // [(S+1)][3]
-    const R *tm;     // [S]
-    R *co;           // segment k's record at co + k*seg_stride: [3][2O]
+template <int O, typename IO> struct TrajView {
+    const IO *wp;    // [(S+1)][3]
+    const IO *tm;    // [S]
+    IO *co;          // segment k's record at co + k*seg_stride: [3][2O]
     int64_t seg_stride;  // 3*2O (trajectory-major) or B*3*2O (CSP_FLAG_SEGMENT_MAJOR)
     int S;
 };
 
 // One full solve pass.  path_on selects the penalised system (second pass of :347-469).
 // Returns status bits; writes coefficients; if dev_out != nullptr also the deviation metric.
-template <int O, typename R>
-__device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1 : 1)][3],
+template <int O, typename IO, typename R>
+__device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 1 : 1)][3],
                           const R (&xS)[(O > 1 ? O - 1 : 1)][3], bool path_on, R pw, R vw,
                           R *ws, const int *tstar, int64_t B, int64_t b, double *dev_out) {
     constexpr int N = O - 1;
@@ -46,15 +47,15 @@ __device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1
             for (int ax = 0; ax < 3; ++ax) z[r][ax] = x0[r][ax];
         }
         R Pp[3], Pc[3], Pn[3];
-        load3<O, R>(tv.wp, Pp);
-        load3<O, R>(tv.wp + 3, Pc);
+        load3<IO, R>(tv.wp, Pp);
+        load3<IO, R>(tv.wp + 3, Pc);
         SegBlocks<O, R> left, right;
-        if (path_on) seg_blocks<O, R, true>(tv.tm[0], vw, pw, tstar[0 * B], Pp, Pc, left);
-        else seg_blocks<O, R, false>(tv.tm[0], vw, pw, 0, Pp, Pc, left);
+        if (path_on) seg_blocks<O, R, true>(R(tv.tm[0]), vw, pw, tstar[0 * B], Pp, Pc, left);
+        else seg_blocks<O, R, false>(R(tv.tm[0]), vw, pw, 0, Pp, Pc, left);
         for (int k = 1; k < S; ++k) {
-            load3<O, R>(tv.wp + 3 * (k + 1), Pn);
-            if (path_on) seg_blocks<O, R, true>(tv.tm[k], vw, pw, tstar[(int64_t)k * B], Pc, Pn, right);
-            else seg_blocks<O, R, false>(tv.tm[k], vw, pw, 0, Pc, Pn, right);
+            load3<IO, R>(tv.wp + 3 * (k + 1), Pn);
+            if (path_on) seg_blocks<O, R, true>(R(tv.tm[k]), vw, pw, tstar[(int64_t)k * B], Pc, Pn, right);
+            else seg_blocks<O, R, false>(R(tv.tm[k]), vw, pw, 0, Pc, Pn, right);
             R A[NS][NS], Bm[NS][NS + 3];
 #pragma unroll
             for (int r = 0; r < N; ++r) {
@@ -121,10 +122,10 @@ __device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1
                     xk[r][ax] = v;
                 }
         }
-        const R T = tv.tm[k];
+        const R T = R(tv.tm[k]);
         R P0[3], P1[3];
-        load3<O, R>(tv.wp + 3 * k, P0);
-        load3<O, R>(tv.wp + 3 * (k + 1), P1);
+        load3<IO, R>(tv.wp + 3 * k, P0);
+        load3<IO, R>(tv.wp + 3 * (k + 1), P1);
         R tp[O], ip[M];
         tp[0] = R(1);
 #pragma unroll
@@ -143,9 +144,9 @@ __device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1
 #pragma unroll
             for (int r = 0; r < N; ++r) { d[r + 1] = xk[r][ax]; d[O + r + 1] = xn[r][ax]; }
             recover_axis<O, R>(d, tp, ip, c);
-            R *dst = tv.co + (int64_t)k * tv.seg_stride + ax * M;
+            IO *dst = tv.co + (int64_t)k * tv.seg_stride + ax * M;
 #pragma unroll
-            for (int i = 0; i < M; ++i) { dst[i] = c[i]; nanacc = fma_<R>(c[i], R(0), nanacc); }
+            for (int i = 0; i < M; ++i) { dst[i] = IO(c[i]); nanacc = fma_<R>(R(dst[i]) , R(0), nanacc); }
             if (dev_out) {
                 // deviation at the recorded t* (minimum_snap.cpp:596-617); t* = 0 without path penalty
                 const R ts = T * tau;
@@ -175,19 +176,19 @@ __device__ int solve_pass(const TrajView<O, R> &tv, const R (&x0)[(O > 1 ? O - 1
 
 // Picks t*_k = argmax over 17 samples of the squared distance between the pre-solve polynomial
 // and the chord (minimum_snap.cpp:408-439; strict '>' so the first maximum wins).
-template <int O, typename R>
-__device__ void pick_tstar(const TrajView<O, R> &tv, int *tstar, int64_t B) {
+template <int O, typename IO, typename R>
+__device__ void pick_tstar(const TrajView<O, IO> &tv, int *tstar, int64_t B) {
     constexpr int M = 2 * O;
     for (int k = 0; k < tv.S; ++k) {
-        const R T = tv.tm[k];
+        const R T = R(tv.tm[k]);
         R P0[3], P1[3];
-        load3<O, R>(tv.wp + 3 * k, P0);
-        load3<O, R>(tv.wp + 3 * (k + 1), P1);
+        load3<IO, R>(tv.wp + 3 * k, P0);
+        load3<IO, R>(tv.wp + 3 * (k + 1), P1);
         R c[3][M];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
-            for (int i = 0; i < M; ++i) c[ax][i] = tv.co[(int64_t)k * tv.seg_stride + ax * M + i];
+            for (int i = 0; i < M; ++i) c[ax][i] = R(tv.co[(int64_t)k * tv.seg_stride + ax * M + i]);
         int best = 0;
         R bestd = R(-1);
         for (int s = 0; s <= 16; ++s) {
@@ -207,7 +208,7 @@ __device__ void pick_tstar(const TrajView<O, R> &tv, int *tstar, int64_t B) {
     }
 }
 
-template <int O, typename R>
+template <int O, typename IO, typename R>
 __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     constexpr int N = O - 1;
     constexpr int NS = (O > 1) ? O - 1 : 1;
@@ -219,13 +220,13 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     if (a.seg_off) { seg0 = a.seg_off[b]; S = (int)(a.seg_off[b + 1] - seg0); }
     else { seg0 = b * (int64_t)a.S; S = a.S; }
     if (S < 1) { if (a.status) a.status[b] = 0; if (a.max_dev) a.max_dev[b] = 0.0; return; }
-    TrajView<O, R> tv;
-    tv.wp = (const R *)a.wp + (seg0 + b) * 3;
-    tv.tm = (const R *)a.times + seg0;
-    if (a.seg_major && !a.seg_off) { tv.co = (R *)a.coeffs + b * 3 * M; tv.seg_stride = a.B * 3 * M; }
-    else { tv.co = (R *)a.coeffs + seg0 * 3 * M; tv.seg_stride = 3 * M; }
+    TrajView<O, IO> tv;
+    tv.wp = (const IO *)a.wp + (seg0 + b) * 3;
+    tv.tm = (const IO *)a.times + seg0;
+    if (a.seg_major && !a.seg_off) { tv.co = (IO *)a.coeffs + b * 3 * M; tv.seg_stride = a.B * 3 * M; }
+    else { tv.co = (IO *)a.coeffs + seg0 * 3 * M; tv.seg_stride = 3 * M; }
     tv.S = S;
-    const R *bc = (const R *)a.bc + (a.bc_per_traj ? b * 12 : 0);
+    const IO *bc = (const IO *)a.bc + (a.bc_per_traj ? b * 12 : 0);
     // fixed boundary derivatives (minimum_snap.cpp:527-555): velocity if order>=2,
     // acceleration if order>=3, every higher one is pinned to zero (:225)
     R x0[NS][3], xS[NS][3];
@@ -233,8 +234,8 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     for (int r = 0; r < NS; ++r)
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            x0[r][ax] = (r < N && r == 0) ? bc[0 * 3 + ax] : (r < N && r == 1) ? bc[2 * 3 + ax] : R(0);
-            xS[r][ax] = (r < N && r == 0) ? bc[1 * 3 + ax] : (r < N && r == 1) ? bc[3 * 3 + ax] : R(0);
+            x0[r][ax] = (r < N && r == 0) ? R(bc[0 * 3 + ax]) : (r < N && r == 1) ? R(bc[2 * 3 + ax]) : R(0);
+            xS[r][ax] = (r < N && r == 0) ? R(bc[1 * 3 + ax]) : (r < N && r == 1) ? R(bc[3 * 3 + ax]) : R(0);
         }
     R *ws = (R *)a.ws + b;
     int *tstar = a.tstar ? a.tstar + b : nullptr;
@@ -243,37 +244,40 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     int status = 0;
     double dev = 0.0;
     if (a.path_weight > 0.0) {
-        status |= solve_pass<O, R>(tv, x0, xS, false, R(0), R(0), ws, tstar, a.B, b, nullptr);
-        pick_tstar<O, R>(tv, tstar, a.B);
-        status = solve_pass<O, R>(tv, x0, xS, true, pw, vw, ws, tstar, a.B, b, &dev);
+        status |= solve_pass<O, IO, R>(tv, x0, xS, false, R(0), R(0), ws, tstar, a.B, b, nullptr);
+        pick_tstar<O, IO, R>(tv, tstar, a.B);
+        status = solve_pass<O, IO, R>(tv, x0, xS, true, pw, vw, ws, tstar, a.B, b, &dev);
     } else {
-        status = solve_pass<O, R>(tv, x0, xS, false, R(0), vw, ws, tstar, a.B, b, a.max_dev ? &dev : nullptr);
+        status = solve_pass<O, IO, R>(tv, x0, xS, false, R(0), vw, ws, tstar, a.B, b, a.max_dev ? &dev : nullptr);
     }
     if (a.status) a.status[b] = status;
     if (a.max_dev) a.max_dev[b] = dev;
 }
 
-template <int O, typename R> static hipError_t launch_o(const GenericArgs &a, hipStream_t st) {
+template <int O, typename IO, typename R> static hipError_t launch_o(const GenericArgs &a, hipStream_t st) {
     if (a.B == 0) return hipSuccess;
     const int threads = 256;
     const int64_t blocks = (a.B + threads - 1) / threads;
-    hipLaunchKernelGGL((minsnap_generic_kernel<O, R>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL((minsnap_generic_kernel<O, IO, R>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
     return hipGetLastError();
 }
 
-template <typename R> static hipError_t launch_r(const GenericArgs &a, hipStream_t st) {
+template <typename IO, typename R> static hipError_t launch_r(const GenericArgs &a, hipStream_t st) {
     switch (a.order) {
-        case 1: return launch_o<1, R>(a, st);
-        case 2: return launch_o<2, R>(a, st);
-        case 3: return launch_o<3, R>(a, st);
-        case 4: return launch_o<4, R>(a, st);
-        case 5: return launch_o<5, R>(a, st);
+        case 1: return launch_o<1, IO, R>(a, st);
+        case 2: return launch_o<2, IO, R>(a, st);
+        case 3: return launch_o<3, IO, R>(a, st);
+        case 4: return launch_o<4, IO, R>(a, st);
+        case 5: return launch_o<5, IO, R>(a, st);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_generic(const GenericArgs &a, bool f32, hipStream_t st) {
-    return f32 ? launch_r<float>(a, st) : launch_r<double>(a, st);
+// f32 storage computes in f64 unless f32_arith is set (CSP_FLAG_F32_ARITH): pure-f32 arithmetic
+// loses 3..5 digits at order 4..5 (tests/test_gpu_parity.py::test_f32_storage).
+hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st) {
+    if (!f32) return launch_r<double, double>(a, st);
+    return f32_arith ? launch_r<float, float>(a, st) : launch_r<float, double>(a, st);
 }
 
 size_t generic_ws_entries(int order) {

@@ -31,7 +31,7 @@ struct GenericArgs {
     int persistent;         // fixed kernel: persistent workgroups with LDS-DMA prefetch (default on)
 };
 
-hipError_t launch_generic(const GenericArgs &a, bool f32, hipStream_t st);
+hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
 size_t generic_ws_entries(int order);
 
 // Fixed-size register-resident kernel (minsnap_fixed.hip).  Serves order 4, f64, uniform even

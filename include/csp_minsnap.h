@@ -63,6 +63,9 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
                                        (segment, trajectory) record keeps the reference's row
                                        content (3*p_num1d values, highest power first) */
 
+#define CSP_FLAG_F32_ARITH 0x8u      /* CSP_DTYPE_F32 only: compute in fp32 too.  By default fp32 is
+                                       the STORAGE type and the arithmetic is fp64 (pure fp32 loses
+                                       3..5 digits at order 4..5) */
 #define CSP_FLAG_NO_PERSISTENT 0x4u  /* fixed kernel: one workgroup per 64 trajectories instead of
                                        persistent workgroups with LDS-DMA prefetch (A/B testing) */
 
@@ -73,7 +76,7 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 
 typedef struct csp_minsnap_desc {
     uint32_t abi_version;       /* CSP_MINSNAP_ABI_VERSION                                       */
-    uint32_t dtype;             /* CSP_DTYPE_F64 | CSP_DTYPE_F32: type of waypoints/times/bc/coeffs */
+    uint32_t dtype;             /* CSP_DTYPE_F64 | CSP_DTYPE_F32: STORAGE type of waypoints/times/bc/coeffs */
     int32_t order;              /* derivative order d_order (reference `order`): 4 = min-snap,
                                    polynomial degree 2*order-1 (minimum_snap.cpp:237-238)         */
     int32_t num_segments;       /* uniform S >= 1, or 0 for a ragged batch                         */

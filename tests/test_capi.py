@@ -54,6 +54,8 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(d) == "generic_o4_f64"
     assert csp.workspace_bytes(d) >= 15 * 18 * 10 * 8 + 16 * 10 * 4
     d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32)
+    assert csp.kernel_name(d) == "generic_o3_f32io_f64"
+    d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32, flags=csp.FLAG_F32_ARITH)
     assert csp.kernel_name(d) == "generic_o3_f32"
     assert csp.kernel_name(csp.make_desc(6, 1, 4)) is None          # unsupported order
     assert csp.kernel_name(csp.make_desc(4, 1, 0)) is None          # ragged without offsets

@@ -100,6 +100,35 @@ def test_segment_major_layout(csp, B):
         assert np.array_equal(np.transpose(b, (1, 0, 2, 3)), a)
 
 
+def test_f32_storage_mixed_batch_c5(csp, oracle_mod):
+    """BASELINE config C5 shape: S ~ U{4..64}, order ~ U{3,4,5}, fp32 storage, bucketed ragged path.
+    The reference defines no fp32 behaviour (parity unpinned, builder-defined gates): with the
+    default fp64 arithmetic the only loss is the final rounding to fp32 (gate 1e-6 relative to the
+    fp64 oracle run on the same fp32-rounded inputs); pure fp32 arithmetic (CSP_FLAG_F32_ARITH) is
+    gated at 1e-3 / 5e-3 / 1e-1 for order 3 / 4 / 5 and its measured error is printed."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("csp_mixed", os.path.join(os.path.dirname(csp.__file__), "mixed.py"))
+    mixed = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mixed)
+    trajs = synth.make_ragged(240)
+    got, kernels = mixed.solve_mixed(trajs, dtype=np.float32)
+    assert all(k.startswith("generic_o") and k.endswith("f32io_f64_ragged") for k in kernels), kernels
+    got32, _ = mixed.solve_mixed(trajs, dtype=np.float32, f32_arith=True)
+    worst = {3: 0.0, 4: 0.0, 5: 0.0}
+    worst32 = {3: 0.0, 4: 0.0, 5: 0.0}
+    z = np.zeros((2, 3))
+    for (o, w, t), c, c32 in zip(trajs, got, got32):
+        w32, t32 = w.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
+        ref, _ = oracle_mod.solve(o, w32, z, z, t32, long_double=True)
+        den = np.max(np.abs(ref))
+        worst[o] = max(worst[o], float(np.max(np.abs(c.astype(np.float64).reshape(ref.shape) - ref)) / den))
+        worst32[o] = max(worst32[o], float(np.max(np.abs(c32.astype(np.float64).reshape(ref.shape) - ref)) / den))
+    print("C5 f32 storage / f64 arithmetic worst rel err per order:", worst)
+    print("C5 f32 storage / f32 arithmetic worst rel err per order:", worst32)
+    assert all(v < 1e-6 for v in worst.values()), worst
+    assert worst32[3] < 1e-3 and worst32[4] < 5e-3 and worst32[5] < 1e-1, worst32
+
+
 def test_ragged_batch(csp, oracle_mod):
     trajs = [t for t in synth.make_ragged(96, smin=1, smax=40) if t[0] == 4]
     wp = np.concatenate([t[1] for t in trajs])
