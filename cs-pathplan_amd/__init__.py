@@ -38,6 +38,7 @@ TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
     "csp_minsnap_solve_batch", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
+    "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
 )
@@ -77,6 +78,14 @@ _lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_time_alloc_batch.restype = ctypes.c_int
 _lib.csp_minsnap_time_alloc_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+_lib.csp_minsnap_plan_batch.restype = ctypes.c_int
+_lib.csp_minsnap_plan_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double, ctypes.c_double] + \
+    [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p]
+_lib.csp_minsnap_plan_workspace_bytes.restype = ctypes.c_size_t
+_lib.csp_minsnap_plan_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
+_lib.csp_minsnap_sample_batch.restype = ctypes.c_int
+_lib.csp_minsnap_sample_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 _lib.csp_minsnap_kernel_name.restype = ctypes.c_char_p
 _lib.csp_minsnap_kernel_name.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_device_count.restype = ctypes.c_int
@@ -298,3 +307,91 @@ def time_alloc_batch(waypoints, v_avg, min_time_s, seg_offsets=None, stream=None
     _check(_lib.csp_minsnap_time_alloc_batch(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg),
                                              float(min_time_s), times.ctypes.data, None))
     return times
+
+
+class Plan:
+    __slots__ = ("times", "coeffs", "max_dev", "vel_zero_weight", "iterations", "status")
+
+
+def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, vel_zero_weight=0.0):
+    """Batched solver half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:59-90): time
+    allocation + the <=10x vel_zero_weight doubling loop.  Uniform batches, numpy (host) or torch
+    CUDA tensors.  waypoints [B,S+1,3]."""
+    on_device = _is_torch(waypoints)
+    m = 2 * int(order)
+    r = Plan()
+    if on_device:
+        import torch
+        dev, tdt = waypoints.device, waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        waypoints = waypoints.contiguous()
+        B, S = waypoints.shape[0], waypoints.shape[1] - 1
+        bc = torch.zeros((1, 4, 3), dtype=tdt, device=dev) if bc is None else bc.to(tdt).contiguous().reshape(-1, 4, 3)
+        r.times = torch.empty((B, S), dtype=tdt, device=dev)
+        r.coeffs = torch.empty((B, S, 3, m), dtype=tdt, device=dev)
+        r.max_dev = torch.empty(B, dtype=torch.float64, device=dev)
+        r.vel_zero_weight = torch.empty(B, dtype=torch.float64, device=dev)
+        r.iterations = torch.empty(B, dtype=torch.int32, device=dev)
+        r.status = torch.empty(B, dtype=torch.int32, device=dev)
+        desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, bc.shape[0] == B and B != 1,
+                         device_id=dev.index if dev.index is not None else -1)
+        need = int(_lib.csp_minsnap_plan_workspace_bytes(ctypes.byref(desc)))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _check(_lib.csp_minsnap_plan_batch(ctypes.byref(desc), waypoints.data_ptr(), float(v_avg), float(min_time_s),
+                                           bc.data_ptr(), r.times.data_ptr(), r.coeffs.data_ptr(), r.max_dev.data_ptr(),
+                                           r.vel_zero_weight.data_ptr(), r.iterations.data_ptr(), r.status.data_ptr(),
+                                           ws.data_ptr(), need, ctypes.c_void_p(st)))
+        return r
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    waypoints = np.ascontiguousarray(waypoints, dtype=npdt)
+    B, S = waypoints.shape[0], waypoints.shape[1] - 1
+    bc = np.zeros((1, 4, 3), dtype=npdt) if bc is None else np.ascontiguousarray(bc, dtype=npdt).reshape(-1, 4, 3)
+    r.times = np.empty((B, S), dtype=npdt)
+    r.coeffs = np.empty((B, S, 3, m), dtype=npdt)
+    r.max_dev = np.empty(B, dtype=np.float64)
+    r.vel_zero_weight = np.empty(B, dtype=np.float64)
+    r.iterations = np.empty(B, dtype=np.int32)
+    r.status = np.empty(B, dtype=np.int32)
+    desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_HOST, bc.shape[0] == B and B != 1)
+    _check(_lib.csp_minsnap_plan_batch(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg), float(min_time_s),
+                                       bc.ctypes.data, r.times.ctypes.data, r.coeffs.ctypes.data, r.max_dev.ctypes.data,
+                                       r.vel_zero_weight.ctypes.data, r.iterations.ctypes.data, r.status.ctypes.data,
+                                       None, 0, None))
+    return r
+
+
+def sample_batch(times, coeffs, sample_distance, capacity, order=None):
+    """Batched sampling half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:97-205).
+    times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2])."""
+    on_device = _is_torch(times)
+    B, S = times.shape
+    order = int(order) if order is not None else int(coeffs.shape[-1]) // 2
+    if on_device:
+        import torch
+        dev, tdt = times.device, times.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        times, coeffs = times.contiguous(), coeffs.to(tdt).contiguous()
+        samples = torch.zeros((B, capacity, 3), dtype=tdt, device=dev)
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
+        desc = make_desc(order, B, S, dtype, mem_space=MEM_DEVICE, device_id=dev.index if dev.index is not None else -1)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.data_ptr(), coeffs.data_ptr(), float(sample_distance),
+                                             int(capacity), samples.data_ptr(), counts.data_ptr(), stats.data_ptr(),
+                                             ctypes.c_void_p(st)))
+        return samples, counts, stats
+    times = np.asarray(times)
+    dtype = DTYPE_F32 if times.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    times = np.ascontiguousarray(times, dtype=npdt)
+    coeffs = np.ascontiguousarray(coeffs, dtype=npdt)
+    samples = np.zeros((B, capacity, 3), dtype=npdt)
+    counts = np.empty(B, dtype=np.int32)
+    stats = np.empty((B, 2), dtype=np.float64)
+    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST)
+    _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.ctypes.data, coeffs.ctypes.data, float(sample_distance),
+                                         int(capacity), samples.ctypes.data, counts.ctypes.data, stats.ctypes.data, None))
+    return samples, counts, stats

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -98,7 +99,7 @@ struct DevBuf {
 
 int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const void *tm, const void *bc,
              void *co, double *max_dev, int32_t *status, const int64_t *seg_off, const double *vw_per,
-             void *ws, size_t ws_size, hipStream_t st) {
+             void *ws, size_t ws_size, hipStream_t st, const int32_t *skip = nullptr) {
     size_t tstar_off = 0;
     const size_t need = ws_bytes(d, s, &tstar_off);
     if (need > 0 && (!ws || ws_size < need)) return CSP_ERR_WORKSPACE;
@@ -115,6 +116,7 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.Btotal = s.B;
     a.Boffset = 0;
     a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
+    a.skip = skip;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;
@@ -255,6 +257,159 @@ int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypo
     hipError_t e = csp::launch_time_alloc(a, s.f32, st);
     if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
     CSP_HIP(hipMemcpyAsync(times, d_tm.p, n_tm, hipMemcpyDeviceToHost, st));
+    CSP_HIP(hipStreamSynchronize(st));
+    return CSP_OK;
+}
+
+size_t csp_minsnap_plan_workspace_bytes(const csp_minsnap_desc *desc) {
+    Shape s;
+    if (validate(desc, s) != CSP_OK) return 0;
+    csp_minsnap_desc g = *desc;
+    if (desc->path_weight > 0.0) g.flags |= CSP_FLAG_FORCE_GENERIC;
+    Shape gs;
+    validate(&g, gs);
+    // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32
+    return align_up(ws_bytes(&g, gs, nullptr), 256) + align_up((size_t)s.B * 8, 256) * 2 + align_up((size_t)s.B * 4, 256) * 2;
+}
+
+int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
+                           const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
+                           int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes,
+                           void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !bc || !times || !coeffs) return CSP_ERR_INVALID_ARG;
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+
+    if (desc->mem_space == CSP_MEM_HOST) {
+        // stage through the device, then run the device-memory form
+        const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+        const size_t m = 2 * (size_t)s.order;
+        const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
+        const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
+        DevBuf d_wp, d_tm, d_bc, d_co, d_md, d_vw, d_it, d_st, d_so, d_ws;
+        csp_minsnap_desc dd = *desc;
+        dd.mem_space = CSP_MEM_DEVICE;
+        const size_t n_ws = csp_minsnap_plan_workspace_bytes(&dd);
+        if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm)) || (rc = d_bc.alloc(n_bc)) || (rc = d_co.alloc(n_co)) ||
+            (rc = d_md.alloc((size_t)s.B * 8)) || (rc = d_vw.alloc((size_t)s.B * 8)) || (rc = d_it.alloc((size_t)s.B * 4)) ||
+            (rc = d_st.alloc((size_t)s.B * 4)) || (rc = d_ws.alloc(n_ws)))
+            return rc;
+        CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
+        CSP_HIP(hipMemcpyAsync(d_bc.p, bc, n_bc, hipMemcpyHostToDevice, st));
+        if (s.ragged) {
+            if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
+            CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
+            dd.seg_offsets = (const int64_t *)d_so.p;
+        }
+        dd.vel_zero_weight_per_traj = nullptr;
+        rc = csp_minsnap_plan_batch(&dd, d_wp.p, v_avg, min_time_s, d_bc.p, d_tm.p, d_co.p, (double *)d_md.p,
+                                    (double *)d_vw.p, (int32_t *)d_it.p, (int32_t *)d_st.p, d_ws.p, n_ws, st);
+        if (rc != CSP_OK) return rc;
+        CSP_HIP(hipMemcpyAsync(times, d_tm.p, n_tm, hipMemcpyDeviceToHost, st));
+        CSP_HIP(hipMemcpyAsync(coeffs, d_co.p, n_co, hipMemcpyDeviceToHost, st));
+        if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, d_md.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
+        if (vel_zero_weight_out) CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, d_vw.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
+        if (iterations) CSP_HIP(hipMemcpyAsync(iterations, d_it.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
+        if (status) CSP_HIP(hipMemcpyAsync(status, d_st.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
+        CSP_HIP(hipStreamSynchronize(st));
+        return CSP_OK;
+    }
+
+    // ---- device memory ----
+    csp::TimeAllocArgs ta;
+    ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+    ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
+    hipError_t e = csp::launch_time_alloc(ta, s.f32, st);
+    if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
+
+    if (!(desc->path_weight > 0.0)) {
+        // without the path penalty the deviation metric is identically 0 (t* = 0, :342), so the
+        // loop of :80-90 ends after its first solve
+        rc = dispatch(desc, s, waypoints, times, bc, coeffs, max_dev, status, desc->seg_offsets,
+                      desc->vel_zero_weight_per_traj, workspace, workspace_bytes, st);
+        if (rc != CSP_OK) return rc;
+        if (iterations) CSP_HIP(hipMemsetAsync(iterations, 0, (size_t)s.B * 4, st));
+        if (vel_zero_weight_out) {
+            if (desc->vel_zero_weight_per_traj)
+                CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
+            else if ((e = csp::launch_fill_f64(vel_zero_weight_out, desc->vel_zero_weight, s.B, st)) != hipSuccess)
+                return hip_fail(e, "fill");
+        }
+        return CSP_OK;
+    }
+
+    csp_minsnap_desc g = *desc;
+    g.flags |= CSP_FLAG_FORCE_GENERIC;
+    Shape gs;
+    validate(&g, gs);
+    const size_t need = csp_minsnap_plan_workspace_bytes(desc);
+    if (!workspace || workspace_bytes < need) return CSP_ERR_WORKSPACE;
+    const size_t solve_ws = align_up(ws_bytes(&g, gs, nullptr), 256);
+    char *base = (char *)workspace + solve_ws;
+    double *vw = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
+    double *md = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
+    int32_t *iters = (int32_t *)base;                             base += align_up((size_t)s.B * 4, 256);
+    int32_t *done = (int32_t *)base;
+    if ((e = csp::launch_resolve_init(vw, iters, done, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+    if (desc->vel_zero_weight_per_traj)
+        CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
+    for (int pass = 0; pass <= 10; ++pass) {  // at most 11 solves (:78-90)
+        rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done);
+        if (rc != CSP_OK) return rc;
+        if ((e = csp::launch_resolve_update(md, vw, iters, done, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_update");
+    }
+    if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, md, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
+    if (vel_zero_weight_out) CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, vw, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
+    if (iterations) CSP_HIP(hipMemcpyAsync(iterations, iters, (size_t)s.B * 4, hipMemcpyDeviceToDevice, st));
+    return CSP_OK;
+}
+
+int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, const void *coeffs,
+                             double sample_distance, int64_t capacity, void *samples, int32_t *counts,
+                             double *stats, void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!times || !coeffs || !samples || !counts || capacity < 1) return CSP_ERR_INVALID_ARG;
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    csp::SampleArgs a;
+    a.B = s.B; a.S = s.S; a.order = s.order; a.capacity = capacity; a.sample_distance = sample_distance;
+    a.seg_major = (desc->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
+    if (desc->mem_space == CSP_MEM_DEVICE) {
+        a.times = times; a.coeffs = coeffs; a.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+        a.samples = samples; a.counts = counts; a.stats = stats;
+        hipError_t e = csp::launch_sample(a, s.f32, st);
+        return e == hipSuccess ? CSP_OK : hip_fail(e, "sample launch");
+    }
+    const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    const size_t m = 2 * (size_t)s.order;
+    const size_t n_tm = (size_t)total_seg * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
+    const size_t n_sm = (size_t)s.B * (size_t)capacity * 3 * s.elt;
+    DevBuf d_tm, d_co, d_sm, d_ct, d_sx, d_so;
+    if ((rc = d_tm.alloc(n_tm)) || (rc = d_co.alloc(n_co)) || (rc = d_sm.alloc(n_sm)) || (rc = d_ct.alloc((size_t)s.B * 4)) ||
+        (rc = d_sx.alloc((size_t)s.B * 16)))
+        return rc;
+    CSP_HIP(hipMemcpyAsync(d_tm.p, times, n_tm, hipMemcpyHostToDevice, st));
+    CSP_HIP(hipMemcpyAsync(d_co.p, coeffs, n_co, hipMemcpyHostToDevice, st));
+    if (s.ragged) {
+        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
+        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
+    }
+    a.times = d_tm.p; a.coeffs = d_co.p; a.seg_off = (const int64_t *)d_so.p;
+    a.samples = d_sm.p; a.counts = (int32_t *)d_ct.p; a.stats = (double *)d_sx.p;
+    hipError_t e = csp::launch_sample(a, s.f32, st);
+    if (e != hipSuccess) return hip_fail(e, "sample launch");
+    CSP_HIP(hipMemcpyAsync(samples, d_sm.p, n_sm, hipMemcpyDeviceToHost, st));
+    CSP_HIP(hipMemcpyAsync(counts, d_ct.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
+    if (stats) CSP_HIP(hipMemcpyAsync(stats, d_sx.p, (size_t)s.B * 16, hipMemcpyDeviceToHost, st));
     CSP_HIP(hipStreamSynchronize(st));
     return CSP_OK;
 }

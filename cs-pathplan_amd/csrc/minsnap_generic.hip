@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     constexpr int M = 2 * O;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
+    if (a.skip && a.skip[b]) return;  // re-solve loop: this trajectory already converged
     int64_t seg0;
     int S;
     if (a.seg_off) { seg0 = a.seg_off[b]; S = (int)(a.seg_off[b + 1] - seg0); }

@@ -29,6 +29,7 @@ struct GenericArgs {
     int64_t Btotal;         // seg_major: the batch size the layout is indexed by
     int64_t Boffset;        // seg_major: first trajectory of this launch inside that batch
     int persistent;         // fixed kernel: persistent workgroups with LDS-DMA prefetch (default on)
+    const int32_t *skip;    // generic kernel: [B] non-zero = leave this trajectory untouched (or null)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
@@ -49,5 +50,21 @@ struct TimeAllocArgs {
     double v_avg, min_time_s;
 };
 hipError_t launch_time_alloc(const TimeAllocArgs &a, bool f32, hipStream_t st);
+
+// Re-solve loop bookkeeping (minimum_snap.cpp:80-90) and polynomial sampling (:97-205), minsnap_plan.hip
+hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, double vw0, int64_t B, hipStream_t st);
+hipError_t launch_fill_f64(double *p, double v, int64_t n, hipStream_t st);
+hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int64_t B, hipStream_t st);
+struct SampleArgs {
+    const void *times, *coeffs;
+    const int64_t *seg_off;
+    void *samples;      // [B][capacity][3]
+    int32_t *counts;    // [B]
+    double *stats;      // [B][2] max climb rate, min turn radius (or null)
+    int64_t B, capacity;
+    int S, order, seg_major;
+    double sample_distance;
+};
+hipError_t launch_sample(const SampleArgs &a, bool f32, hipStream_t st);
 
 }  // namespace csp

@@ -3,11 +3,11 @@
 // UavPathPlanner::Minisnap_3D / Minisnap_EN (uavPathPlanning.cpp:4401-4474), which hold a
 // `TrajectoryGeneratorTool generator_` by value (uavPathPlanning.hpp:294), compile unchanged.
 //
-// Every solve goes through the C-ABI (include/csp_minsnap.h) to the HIP kernels: there is no
-// host solver in here.  What stays on the host is the wrapper logic of GenerateTrajectoryMatrix
-// (time allocation, the <=10x re-solve loop, polynomial sampling / distance thinning / stats,
-// minimum_snap.cpp:59-205) -- scalar control flow around the solve; its batched GPU form is the
-// "next" row N1 of SURVEY.md §8f.
+// Everything numeric goes through the C-ABI (include/csp_minsnap.h) to the HIP kernels: there is
+// no host solver, sampler or time allocation in here.  SolveQPClosedForm -> csp_minsnap_solve_batch;
+// GenerateTrajectoryMatrix -> csp_minsnap_plan_batch (time allocation + the <=10x re-solve loop,
+// minimum_snap.cpp:59-90) then csp_minsnap_sample_batch (sampling / distance thinning / statistics,
+// :97-205).  The host only marshals matrices.
 //
 // Matrix types: real Eigen when <Eigen/Dense> exists (then the signatures are the reference's,
 // token for token), otherwise the bundled csp_host mini types (same member names).
@@ -68,6 +68,8 @@ public:
     double last_max_climb_rate = 0.0;
     double last_min_turn_radius = 1.0e12;
     int last_status = CSP_OK;
+    double last_vel_zero_weight = 0.0;   // weight the final solve used (after the :80-90 loop)
+    int last_iterations = 0;
 
     // Replaces minimum_snap.cpp:227-649.  Path W x 3, Vel/Acc 2 x 3 (row 0 start, row 1 end),
     // Time S.  Returns PolyCoeff S x 3*2*order, highest power first (:220-223); an EMPTY matrix
@@ -134,76 +136,56 @@ public:
             return MatrixXd();
         }
         const int S = (int)Path.rows() - 1;
-        VectorXd Time(S);
-        for (int i = 0; i < S; ++i) {  // :63-72
-            const double dx = Path(i + 1, 0) - Path(i, 0), dy = Path(i + 1, 1) - Path(i, 1), dz = Path(i + 1, 2) - Path(i, 2);
-            double t = (V_avg > 1e-6) ? std::sqrt(dx * dx + dy * dy + dz * dz) / V_avg : min_time_s;
-            Time(i) = t < min_time_s ? min_time_s : t;
-        }
-        MatrixXd polyCoeff;
-        double max_dev = 0.0;
-        for (int iter = 0;; ++iter) {  // :80-90
-            polyCoeff = SolveQPClosedForm(order, Path, Vel, Acc, Time, path_weight, vel_zero_weight, &max_dev);
-            if (polyCoeff.size() == 0) return MatrixXd();
-            if (max_dev > 0.2 && iter < 10) {
-                vel_zero_weight = (vel_zero_weight < 1e-6) ? 0.01 : vel_zero_weight * 2.0;
-                if (verbose) std::cout << "Iteration " << iter + 1 << ": max_dev=" << max_dev << " > 0.2. Increasing vel_zero_weight to " << vel_zero_weight << std::endl;
-            } else {
-                break;
-            }
-        }
         const int m = 2 * order;
-        auto eval = [&](int seg, double t, double out[3]) {  // :104-117 (std::pow per term, same order)
-            for (int dim = 0; dim < 3; ++dim) {
-                double val = 0.0;
-                for (int k = 0; k < m; ++k) val += polyCoeff(seg, dim * m + k) * std::pow(t, m - 1 - k);
-                out[dim] = val;
-            }
-        };
-        std::vector<double> samples;
-        samples.reserve(3000);
-        auto push = [&](const double p[3]) { samples.push_back(p[0]); samples.push_back(p[1]); samples.push_back(p[2]); };
-        double prev[3] = {0, 0, 0}, cur[3];
-        for (int seg = 0; seg < S; ++seg) {  // :123-161
-            const double T = Time(seg);
+        std::vector<double> wp((size_t)(S + 1) * 3), bc(12), tm((size_t)S), co((size_t)S * 3 * m);
+        for (int i = 0; i <= S; ++i)
+            for (int a = 0; a < 3; ++a) wp[(size_t)i * 3 + a] = Path(i, a);
+        for (int a = 0; a < 3; ++a) {
+            bc[0 + a] = Vel(0, a); bc[3 + a] = Vel(1, a);
+            bc[6 + a] = Acc(0, a); bc[9 + a] = Acc(1, a);
+        }
+        csp_minsnap_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.abi_version = CSP_MINSNAP_ABI_VERSION;
+        d.dtype = CSP_DTYPE_F64;
+        d.order = order;
+        d.num_segments = S;
+        d.batch = 1;
+        d.path_weight = path_weight;
+        d.vel_zero_weight = vel_zero_weight;
+        d.mem_space = CSP_MEM_HOST;
+        d.device_id = -1;
+        // time allocation (:63-72) + re-solve loop (:80-90) on the device
+        double max_dev = 0.0, vw_final = vel_zero_weight;
+        int32_t iters = 0;
+        last_status = csp_minsnap_plan_batch(&d, wp.data(), V_avg, min_time_s, bc.data(), tm.data(), co.data(),
+                                             &max_dev, &vw_final, &iters, nullptr, nullptr, 0, nullptr);
+        if (last_status != CSP_OK) {
+            std::cerr << "TrajectoryGeneratorTool::GenerateTrajectoryMatrix: " << csp_minsnap_strerror(last_status)
+                      << " " << csp_minsnap_last_hip_error() << std::endl;
+            return MatrixXd();
+        }
+        last_vel_zero_weight = vw_final;
+        last_iterations = iters;
+        if (verbose && iters > 0) std::cout << "vel_zero_weight increased " << iters << "x to " << vw_final << " (max_dev=" << max_dev << ")" << std::endl;
+        // sampling, thinning and statistics (:97-195) on the device; capacity = every evaluation point
+        int64_t cap = 2;
+        for (int i = 0; i < S; ++i) {
             double dt = 0.1;
-            if (dt > T / 10.0) dt = T / 10.0;
-            double t0[3];
-            eval(seg, 0.0, t0);
-            if (samples.empty()) push(t0);
-            std::memcpy(prev, t0, sizeof prev);
-            for (double t = dt; t <= T + 1e-12; t += dt) {
-                eval(seg, t < T ? t : T, cur);
-                const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
-                if (std::sqrt(dx * dx + dy * dy + dz * dz) >= sample_distance) { std::memcpy(prev, cur, sizeof prev); push(cur); }
-            }
-            if (seg == S - 1) {
-                eval(seg, T, cur);
-                const size_t n = samples.size();
-                const double dx = samples[n - 3] - cur[0], dy = samples[n - 2] - cur[1], dz = samples[n - 1] - cur[2];
-                if (std::sqrt(dx * dx + dy * dy + dz * dz) > 1e-6) push(cur);
-            }
+            if (dt > tm[(size_t)i] / 10.0) dt = tm[(size_t)i] / 10.0;
+            cap += (int64_t)((tm[(size_t)i] + 1e-12) / dt) + 2;
         }
-        const long n = (long)(samples.size() / 3);
-        last_max_climb_rate = 0.0;  // :163-195
-        last_min_turn_radius = 1.0e12;
-        for (long i = 0; i + 1 < n; ++i) {
-            const double *p1 = &samples[(size_t)i * 3], *p2 = &samples[(size_t)(i + 1) * 3];
-            const double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = std::fabs(p2[2] - p1[2]);
-            const double hd = std::sqrt(dx * dx + dy * dy);
-            if (hd > 1e-6 && dz / hd > last_max_climb_rate) last_max_climb_rate = dz / hd;
-            if (i > 0) {
-                const double *p0 = &samples[(size_t)(i - 1) * 3];
-                const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-                const double w[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-                const double a = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-                const double b = std::sqrt((p2[0] - p1[0]) * (p2[0] - p1[0]) + (p2[1] - p1[1]) * (p2[1] - p1[1]) + (p2[2] - p1[2]) * (p2[2] - p1[2]));
-                const double c = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-                const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
-                const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
-                if (area > 1e-8) { const double R = a * b * c / (4.0 * area); if (R < last_min_turn_radius) last_min_turn_radius = R; }
-            }
+        std::vector<double> samples((size_t)cap * 3);
+        int32_t count = 0;
+        double stats[2] = {0.0, 1.0e12};
+        last_status = csp_minsnap_sample_batch(&d, tm.data(), co.data(), sample_distance, cap, samples.data(), &count, stats, nullptr);
+        if (last_status != CSP_OK || count > cap) {
+            std::cerr << "TrajectoryGeneratorTool::GenerateTrajectoryMatrix: sampling failed: " << csp_minsnap_strerror(last_status) << std::endl;
+            return MatrixXd();
         }
+        last_max_climb_rate = stats[0];
+        last_min_turn_radius = stats[1];
+        const long n = (long)count;
         if (verbose) {
             std::cout << "Trajectory Max Climb/Descent Rate: " << last_max_climb_rate << std::endl;
             std::cout << "Trajectory Min Turn Radius: " << last_min_turn_radius << std::endl;

@@ -116,6 +116,35 @@ size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
 int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg,
                                  double min_time_s, void *times, void *hip_stream);
 
+/* Replaces the solver half of TrajectoryGeneratorTool::GenerateTrajectoryMatrix
+ * (minimum_snap.cpp:59-90) for a batch: time allocation (as csp_minsnap_time_alloc_batch) followed
+ * by the re-solve loop -- solve; while max_deviation > 0.2 and fewer than 10 increases:
+ * vel_zero_weight <- (w < 1e-6 ? 0.01 : 2w), solve again -- tracked per trajectory on the device
+ * (no host round trip: converged trajectories are skipped by the later passes).
+ *   times      : out, [B][S] (same layout rules as the solve)
+ *   coeffs     : out
+ *   max_dev    : out, optional [B] f64 (final deviation metric)
+ *   vel_zero_weight_out : optional [B] f64, the weight the final solve used
+ *   iterations : optional [B] i32, number of weight increases (reference `iter`)
+ *   workspace  : >= csp_minsnap_plan_workspace_bytes(desc) bytes (device); NULL/0 with CSP_MEM_HOST */
+int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
+                           const void *bc, void *times, void *coeffs, double *max_dev,
+                           double *vel_zero_weight_out, int32_t *iterations, int32_t *status,
+                           void *workspace, size_t workspace_bytes, void *hip_stream);
+size_t csp_minsnap_plan_workspace_bytes(const csp_minsnap_desc *desc);
+
+/* Replaces the sampling half of GenerateTrajectoryMatrix (minimum_snap.cpp:97-205): evaluates each
+ * trajectory at dt = min(0.1, T_seg/10), keeps a point whenever it is >= sample_distance away from
+ * the previously kept one, appends the end point, and computes the two statistics the reference
+ * prints (max climb/descent rate, min turn radius).
+ *   samples : out, [B][capacity][3] (storage dtype); trajectory b uses the first counts[b] rows
+ *   counts  : out, [B] i32 -- the TRUE number of samples; rows beyond `capacity` are dropped, so
+ *             counts[b] > capacity tells the caller to retry with a larger capacity
+ *   stats   : optional out, [B][2] f64 = {max climb rate, min turn radius} */
+int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, const void *coeffs,
+                             double sample_distance, int64_t capacity, void *samples, int32_t *counts,
+                             double *stats, void *hip_stream);
+
 /* Name of the kernel csp_minsnap_solve_batch would dispatch for `desc` ("fixed_o4_s16_f64",
  * "generic_o4_f64", ...); NULL for an invalid descriptor.  For tests and profiles. */
 const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc);

@@ -1,0 +1,67 @@
+"""Batched GenerateTrajectoryMatrix pieces on the GPU against the oracle's
+restatement of minimum_snap.cpp:22-206: time allocation + re-solve loop (csp_minsnap_plan_batch) and
+sampling / distance thinning / statistics (csp_minsnap_sample_batch)."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(oracle_mod, P, **kw):
+    s, info = oracle_mod.generate_trajectory(P, **kw)
+    return s, info
+
+
+@pytest.mark.parametrize("order,pw,vw", [(3, 0.0, 0.0), (4, 0.0, 0.02), (3, 0.5, 0.0), (2, 1e-2, 0.01), (4, 0.3, 0.0)])
+def test_plan_then_sample_matches_oracle(csp, oracle_mod, order, pw, vw):
+    B, S = 24, 6
+    wp, _ = synth.make_batch(B, S, config_id=21)
+    wp = wp * 4.0
+    v_avg, min_t, sd = 5.0, 0.1, 0.7
+    plan = csp.plan_batch(wp, v_avg, min_t, order=order, path_weight=pw, vel_zero_weight=vw)
+    assert not plan.status.any()
+    cap = 4096
+    samples, counts, stats = csp.sample_batch(plan.times, plan.coeffs, sd, cap)
+    n_loop = 0
+    for b in range(B):
+        ref, info = _ref(oracle_mod, wp[b], order=order, path_weight=pw, vel_zero_weight=vw, v_avg=v_avg,
+                         min_time_s=min_t, sample_distance=sd)
+        n_loop += info["iters"] > 0
+        assert np.allclose(plan.times[b], info["time"], rtol=0, atol=1e-15 * np.max(info["time"]))
+        assert plan.iterations[b] == info["iters"], (b, plan.iterations[b], info["iters"])
+        assert abs(plan.vel_zero_weight[b] - info["vel_zero_weight"]) <= 1e-15
+        assert abs(plan.max_dev[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
+        scale = np.max(np.abs(info["coeff"]))
+        assert np.max(np.abs(plan.coeffs[b] - info["coeff"])) < 1e-7 * scale
+        assert counts[b] == len(ref), (b, counts[b], len(ref))
+        assert np.max(np.abs(samples[b, :counts[b]] - ref)) < 1e-7 * np.max(np.abs(ref))
+        assert abs(stats[b, 0] - info["max_climb_rate"]) < 1e-6 * max(1.0, info["max_climb_rate"])
+        assert abs(stats[b, 1] - info["min_turn_radius"]) < 1e-5 * max(1.0, info["min_turn_radius"])
+    if pw >= 0.3:
+        assert n_loop > 0, "fixture does not exercise the re-solve loop"
+
+
+def test_sample_capacity_overflow_is_reported(csp):
+    wp, _ = synth.make_batch(4, 4, config_id=22)
+    plan = csp.plan_batch(wp, 5.0, 0.1, order=3)
+    samples, counts, _ = csp.sample_batch(plan.times, plan.coeffs, 1e-9, 8)
+    assert (counts > 8).all()          # true counts come back; only 8 rows were written
+
+
+def test_device_memory_plan_and_sample(csp, oracle_mod):
+    import torch
+    B, S = 512, 8
+    wp, _ = synth.make_batch(B, S, config_id=23)
+    d_wp = torch.from_numpy(wp * 3.0).cuda()
+    plan = csp.plan_batch(d_wp, 5.0, 0.1, order=4)          # fixed kernel path (no path penalty)
+    samples, counts, stats = csp.sample_batch(plan.times, plan.coeffs, 0.5, 2048)
+    torch.cuda.synchronize()
+    host = csp.plan_batch(wp * 3.0, 5.0, 0.1, order=4)
+    assert np.array_equal(plan.coeffs.cpu().numpy(), host.coeffs)
+    for b in (0, 17, 511):
+        ref, info = oracle_mod.generate_trajectory(wp[b] * 3.0, order=4, v_avg=5.0, min_time_s=0.1, sample_distance=0.5)
+        n = int(counts[b])
+        assert n == len(ref)
+        assert np.max(np.abs(samples[b, :n].cpu().numpy() - ref)) < 1e-7 * np.max(np.abs(ref))
