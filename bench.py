@@ -75,11 +75,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switch for a ONE-GPU box (never set by the driver): CSP_BENCH_SHARE_GPU=1 lets N ranks
+    # exercise the multi-rank control flow (sharded inputs, barrier, MAX-reduce) on cuda:0 over gloo.
+    share = os.environ.get("CSP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     csp = importlib.import_module("cs-pathplan_amd")
     B, S, o = args.batch, args.segments, args.order
@@ -115,7 +122,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -161,6 +168,11 @@ def main():
             chk = min(n, 1024)
             got = out.view(S, B, 3, 2 * o).permute(1, 0, 2, 3)[:chk] if args.segment_major else out[:chk]
             res["parity_max_rel_err"] = synth.rel_err(got.cpu().numpy(), ref[:chk])
+            import oracle
+            nld = 128  # 80-bit long-double build of the oracle as the yardstick for both
+            ld, _ = oracle.solve_batch(o, wp[:nld], tm[:nld], nthreads=oracle.max_threads(), long_double=True)
+            res["parity_vs_long_double"] = {"hip": synth.rel_err(got[:nld].cpu().numpy(), ld),
+                                            "cpu_port_fp64": synth.rel_err(ref[:nld], ld), "trajectories": nld}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -80,6 +80,58 @@ def test_seeded_batch_vs_oracle(csp, oracle_mod, S, B):
         assert not r.status.any()
 
 
+@pytest.mark.parametrize("S", [2, 4, 6, 8, 10, 12, 14, 16])
+def test_fixed_kernel_every_bucket_and_ragged_tails(csp, oracle_mod, S):
+    """Every fixed-size bucket (even S <= 16), batch sizes around the 64-trajectory slice boundary,
+    per-trajectory boundary conditions and per-trajectory zero-velocity weights."""
+    rng = np.random.default_rng(100 + S)
+    for B in (1, 63, 64, 65, 130):
+        wp, tm = synth.make_batch(B, S, config_id=30 + S)
+        bc = rng.normal(size=(B, 4, 3))
+        vw = rng.uniform(0.0, 0.5, size=B)
+        r = csp.solve_batch(wp, tm, bc, order=4, vel_zero_weight_per_traj=vw, want_status=True, want_max_dev=True)
+        assert r.kernel == "fixed_o4_s%d_f64" % S
+        assert not r.status.any() and not r.max_dev.any()
+        g = csp.solve_batch(wp, tm, bc, order=4, vel_zero_weight_per_traj=vw, force_generic=True)
+        assert synth.rel_err(r.coeffs, g.coeffs) < 1e-9, (S, B)
+        for b in (0, B - 1):
+            ref, _ = oracle_mod.solve(4, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], 0.0, float(vw[b]))
+            assert synth.rel_err(r.coeffs[b].reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, (S, B, b)
+
+
+def test_status_flags_bad_trajectories_only(csp):
+    wp, tm = synth.make_batch(130, 16, config_id=3)
+    tm[5, 3] = 0.0        # zero-length segment time -> 1/T = inf -> non-finite coefficients
+    tm[77, 9] = float("nan")
+    for force in (False, True):
+        r = csp.solve_batch(wp, tm, order=4, want_status=True, force_generic=force)
+        bad = np.flatnonzero(r.status)
+        assert bad.tolist() == [5, 77], (r.kernel, bad)
+        good = np.setdiff1d(np.arange(130), bad)
+        assert np.isfinite(r.coeffs[good]).all()
+
+
+def test_large_time_and_length_scales(csp, oracle_mod):
+    """Kilometre-scale waypoints and segment times of minutes (README regime): compare both the HIP
+    result and the dense fp64 oracle with the 80-bit long-double oracle."""
+    wp, tm = synth.make_batch(16, 16, config_id=41)
+    wp = wp * 2000.0
+    tm = tm * 120.0
+    r = csp.solve_batch(wp, tm, order=4)
+    z = np.zeros((2, 3))
+    e_gpu = e_dense = 0.0
+    for b in range(16):
+        ld, _ = oracle_mod.solve(4, wp[b], z, z, tm[b], long_double=True)
+        dn, _ = oracle_mod.solve(4, wp[b], z, z, tm[b])
+        # per-segment, per-power scale: coefficients of t^7 are ~1e-14 of those of t^0 here
+        den = np.max(np.abs(ld.reshape(16, 3, 8)), axis=(0, 1))
+        e_gpu = max(e_gpu, float(np.max(np.abs(r.coeffs[b] - ld.reshape(16, 3, 8)) / den)))
+        e_dense = max(e_dense, float(np.max(np.abs(dn.reshape(16, 3, 8) - ld.reshape(16, 3, 8)) / den)))
+    print("large scales: hip-vs-ld %.2e   dense-fp64-vs-ld %.2e (per-power relative)" % (e_gpu, e_dense))
+    assert e_gpu < NORTH_STAR_TOL
+    assert e_gpu <= 10 * e_dense + 1e-12
+
+
 def test_device_memory_path_matches_host_path(csp):
     import torch
     wp, tm = synth.make_batch(1000, 16, config_id=3)
