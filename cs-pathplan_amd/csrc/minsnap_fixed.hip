@@ -143,12 +143,14 @@ template <int HS> struct FixedLds {
     static constexpr int S = 2 * HS;
     static constexpr int WP_ROW = (S + 1) * 3;       // doubles per trajectory, unpadded (bank-clean for b64 reads)
     static constexpr int TM_ROW = S + 2;             // doubles per trajectory, padded against bank conflicts
-    static constexpr int STAGE_ROW = 26;             // 24 coefficients + 2 pad doubles (208 B rows)
+    static constexpr int STAGE_ROW = 34;             // 24 coefficients + 8 held over from the pair's other
+                                                     // record + 2 pad doubles (272 B rows: conflict-free b128)
     static constexpr int WP_DOUBLES = 64 * WP_ROW;
     static constexpr int TM_DOUBLES = 64 * TM_ROW;
     static constexpr int STAGE_DOUBLES = 64 * STAGE_ROW;  // per wave
-    static constexpr int XCH_DOUBLES = 2 * 15 * 64;
-    static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES + XCH_DOUBLES;
+    // the 15-double Schur carries of the exchange step live at the start of the PARTNER's staging
+    // tile (written before the exchange barrier, read after it, before the tile is used for output)
+    static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES;
 };
 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
@@ -172,7 +174,7 @@ template <int HS> struct RegInputs {                // pulled into registers onc
 // that barrier (the persistent kernel issues the next slice's LDS-DMA there).
 template <int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
-                                           const In &in, double *stage, double (*xch)[15][64],
+                                           const In &in, double *stage, double *partner_stage,
                                            const Hook &after_exchange) {
     constexpr int S = 2 * HS;
     using L = FixedLds<HS>;
@@ -278,37 +280,37 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         }
     }
     {
-        double(*mine)[64] = xch[BOTTOM ? 1 : 0];
+        double *mine = partner_stage;  // the partner reads it from ITS tile after the barrier
         int e = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) mine[e++][lane] = Cm[r][c];
+            for (int c = 0; c <= r; ++c) mine[(e++) * 64 + lane] = Cm[r][c];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) mine[e++][lane] = cm[r][ax];
+            for (int ax = 0; ax < 3; ++ax) mine[(e++) * 64 + lane] = cm[r][ax];
     }
     lds_barrier();
     after_exchange();
     CSP_STAMP(3);
     double xm[3][3];
     {
-        const double(*other)[64] = xch[BOTTOM ? 0 : 1];
+        const double *other = stage;
         double Sm[3][3], I[3][3];
         int e = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c <= r; ++c) {
-                const double o = other[e++][lane];
+                const double o = other[(e++) * 64 + lane];
                 Sm[r][c] = Cm[r][c] + (((r + c) & 1) ? -o : o);
             }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                const double o = other[e++][lane];
+                const double o = other[(e++) * 64 + lane];
                 cm[r][ax] += (r & 1) ? o : -o;  // derivative r+1 is odd for r = 0, 2
             }
         spd &= inv3(Sm, I);
@@ -325,13 +327,25 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
     // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
     double nanacc = 0.0;
-    const int grp = (lane * 43691) >> 19;          // lane / 12 (5 for the idle lanes 60..63)
-    const int lane_in = lane - grp * 12;
-    const int lds_off = grp * L::STAGE_ROW + lane_in * 2;            // doubles
     // bytes between consecutive trajectories' records of one segment: the default layout is
     // [B][S][3][8] (3072-byte stride at S=16); CSP_FLAG_SEGMENT_MAJOR selects [S][B][3][8]
     constexpr int RS = SEGMAJ ? 192 : S * 192;
-    const unsigned g_off = (unsigned)(grp * RS + lane_in * 16); // bytes
+    constexpr int ROW = L::STAGE_ROW;
+    // Output leaves through a lane-major LDS tile and is read back transposed.  In the default
+    // layout the records of segments (2q, 2q+1) of one trajectory form one 384-byte, 128-byte-aligned
+    // run, so a wave pairs them: of the first record it stores the 128 bytes that complete a cache
+    // line and holds the other 64 in the tile; with the second record it stores a 256-byte run.
+    // Every line is then written whole (the single-record scheme left 1/3 of the lines half-written
+    // between two bursts and measured +8 % WRITE_SIZE).  Lane maps for the three burst shapes:
+    constexpr bool PAIRING = FULL && !SEGMAJ;
+    const int grp = (lane * 43691) >> 19;          // 12 lanes per 192-byte record (lanes 60..63 idle)
+    const int lane_in = lane - grp * 12;
+    const int lds_off = grp * ROW + lane_in * 2;   // doubles
+    const unsigned g_off = (unsigned)(grp * RS + lane_in * 16);  // bytes
+    const int l8 = (lane >> 3) * ROW + 8 + (lane & 7) * 2;       // 8 lanes per 128-byte half, tile doubles 8..23
+    const unsigned o8 = (unsigned)((lane >> 3) * RS + (lane & 7) * 16);
+    const int l16 = (lane >> 4) * ROW + (lane & 15) * 2;         // 16 lanes per 256-byte run, tile doubles 0..31
+    const unsigned o16 = (unsigned)((lane >> 4) * RS + (lane & 15) * 16);
     double xn[3][3];  // free derivatives at local waypoint j+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -365,6 +379,9 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         tp[1] = Tj * Tj;
         tp[2] = tp[1] * Tj;
         const int g = BOTTOM ? S - 1 - j : j;  // global segment index
+        // the middle pair of an odd half is split between the two waves: those records go out singly
+        const bool paired = PAIRING && !((HS & 1) && g == (BOTTOM ? HS : HS - 1));
+        const bool first = BOTTOM ? (g & 1) == 0 : (g & 1) == 1;  // first record of its pair to reach this wave
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             double xs[3], xe[3], c[M8];
@@ -380,48 +397,70 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
             const double Ps = BOTTOM ? Phi : Plo;
             const double Pe = BOTTOM ? Plo : Phi;
             recover4(Ps, Pe - Ps, xs, xe, tp, ip, c);
-            // lane-major staging tile: row = lane, 208-byte rows keep ds_write_b128 conflict-free
+            // lane-major staging tile (row = lane, 272-byte rows keep ds_write_b128 conflict-free);
+            // where the axis block lands depends on the record's place in its pair (see below)
+            const int tpos = !paired ? ax * M8
+                           : (!BOTTOM ? (first ? (ax == 0 ? 24 : ax * M8) : ax * M8)
+                                      : (first ? (ax == 2 ? 0 : 8 + ax * M8) : 8 + ax * M8));
 #pragma unroll
             for (int i = 0; i < M8; i += 2) {
                 double2 v2;
                 v2.x = c[i];
                 v2.y = c[i + 1];
-                *reinterpret_cast<double2 *>(stage + lane * L::STAGE_ROW + ax * M8 + i) = v2;
+                *reinterpret_cast<double2 *>(stage + lane * ROW + tpos + i) = v2;
             }
             if (STATUS) {
 #pragma unroll
                 for (int i = 0; i < M8; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
             }
         }
-        // transposed read-back: 12 consecutive lanes carry the 12 16-byte pieces of one
-        // (trajectory, segment) record, 5 records per wave store.  Lane offsets are loop-invariant.
-        // LDS operations of one wave execute in order, so the staging tile needs no barrier; the
-        // fences only stop the compiler from reordering the (may-alias) LDS accesses.
+        // LDS operations of one wave execute in order, so the tile needs no barrier; the fences only
+        // stop the compiler from reordering the (may-alias) LDS accesses.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        {
+        if (paired) {
+            // pair base = record of the even segment; TOP meets the odd record first, BOTTOM the even one
+            char *pbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + (g & ~1)) * 24);  // uniform
+            if (first) {
+                double2 v[8];   // 8 rows x 128 bytes per store
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l8 + i * 8 * ROW);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 0 : 256) + (size_t)i * 8 * RS + o8) = v[i];
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {  // 4 rows x 256 bytes per store, two batches of 8
+                    double2 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l16 + (h * 8 + i) * 4 * ROW);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 128 : 0) + (size_t)(h * 8 + i) * 4 * RS + o16) = v[i];
+                }
+            }
+        } else {
             char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (SEGMAJ ? ((int64_t)g * a.Btotal + a.Boffset + b0) : (b0 * S + g)) * 24);  // uniform
             if (FULL) {
                 // 12 stores by lanes 0..59 (rows 0..59), a 13th by lanes 0..47 (rows 60..63); idle
-                // lanes are masked off rather than made to repeat a neighbour's piece -- duplicate
-                // stores are real write traffic (they showed up as +6 % WRITE_SIZE)
+                // lanes are masked off, not made to repeat a neighbour's piece (duplicates are traffic)
                 if (lane < 60) {
                     double2 v[12];
 #pragma unroll
                     for (int i = 0; i < 12; ++i)
-                        v[i] = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * L::STAGE_ROW);
+                        v[i] = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * ROW);
 #pragma unroll
                     for (int i = 0; i < 12; ++i)
                         *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + g_off) = v[i];
                     if (lane < 48)
                         *reinterpret_cast<double2 *>(gbase + (size_t)12 * 5 * RS + g_off) =
-                            *reinterpret_cast<const double2 *>(stage + lds_off + 12 * 5 * L::STAGE_ROW);
+                            *reinterpret_cast<const double2 *>(stage + lds_off + 12 * 5 * ROW);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
                     const int row = i * 5 + grp;
                     if (lane < 60 && row < 64 && b0 + row < a.B) {
-                        const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * L::STAGE_ROW);
+                        const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * 5 * ROW);
                         *reinterpret_cast<double2 *>(gbase + (size_t)i * 5 * RS + g_off) = v2;
                     }
                 }
@@ -451,7 +490,6 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     double *l_wp = lds;
     double *l_tm = l_wp + L::WP_DOUBLES;
     double *l_stage = l_tm + L::TM_DOUBLES;
-    double(*xch)[15][64] = reinterpret_cast<double(*)[15][64]>(l_stage + 2 * L::STAGE_DOUBLES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -491,10 +529,10 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
     if (role == 0) {
         const LdsInputs<HS, false> in{l_wp, l_tm, lane};
-        fixed_body<HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage, xch, NoHook{});
+        fixed_body<HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage, l_stage + L::STAGE_DOUBLES, NoHook{});
     } else {
         const LdsInputs<HS, true> in{l_wp, l_tm, lane};
-        fixed_body<HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage + L::STAGE_DOUBLES, xch, NoHook{});
+        fixed_body<HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage + L::STAGE_DOUBLES, l_stage, NoHook{});
     }
 }
 
@@ -535,7 +573,7 @@ template <int HS> struct SlicePrefetch {
 
 template <int HS, bool BOTTOM, bool STATUS, bool SEGMAJ>
 __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n_slices, int lane, const double *l_wp,
-                                                     const double *l_tm, double *stage, double (*xch)[15][64],
+                                                     const double *l_tm, double *stage, double *partner_stage,
                                                      SlicePrefetch<HS> pf) {
     constexpr int S = 2 * HS;
     constexpr int STORES_PER_SLICE = 13 * HS;  // per wave; all younger than that slice's prefetch
@@ -551,7 +589,7 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
         const int64_t b0 = slice * 64;
         pf.next = slice + gridDim.x;
         // the image is dead once both waves passed the exchange barrier: prefetch the next slice there
-        fixed_body<HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, stage, xch, pf);
+        fixed_body<HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, stage, partner_stage, pf);
         first = false;
     }
 }
@@ -563,11 +601,10 @@ template <int HS, bool STATUS, bool SEGMAJ>
 __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericArgs a, int n_slices) {
     using L = FixedLds<HS>;
     constexpr int S = 2 * HS;
-    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES + L::XCH_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES];
     double *l_wp = lds;
     double *l_tm = l_wp + 64 * L::WP_ROW;
     double *l_stage = l_tm + 64 * S;
-    double(*xch)[15][64] = reinterpret_cast<double(*)[15][64]>(l_stage + 2 * L::STAGE_DOUBLES);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int role = tid >> 6;  // wave-uniform
@@ -583,8 +620,8 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
     CSP_STAMP(0);
     if ((int64_t)blockIdx.x < n_slices) pf.issue(blockIdx.x);
     // one loop per role: each wave's instruction stream holds a single specialisation
-    if (role == 0) persistent_role_loop<HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, xch, pf);
-    else persistent_role_loop<HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, xch, pf);
+    if (role == 0) persistent_role_loop<HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, pf);
+    else persistent_role_loop<HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, pf);
 }
 
 }  // namespace
