@@ -117,6 +117,9 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.Boffset = 0;
     a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
     a.skip = skip;
+    // the fixed kernel moves 16-byte pieces (LDS-DMA, ds_read_b128, dwordx4 stores)
+    const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
+    if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;

@@ -19,7 +19,8 @@
  *   - the compute path is HIP on gfx950 only.  There is NO CPU fallback: without a usable
  *     device the calls return CSP_ERR_NO_DEVICE.
  *
- * Data layout (all row-major, contiguous)
+ * Data layout (all row-major, contiguous; device pointers 16-byte aligned -- hipMalloc and torch
+ * allocations are -- or pass CSP_FLAG_FORCE_GENERIC)
  *   waypoints : [B][S+1][3]   positions (reference `Path`, W x 3, minimum_snap.hpp:47)
  *   times     : [B][S]        segment durations (reference `Time`, minimum_snap.hpp:50)
  *   bc        : [B or 1][4][3] rows = start vel, end vel, start acc, end acc
