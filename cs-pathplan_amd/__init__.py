@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
+    "csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch",
 )
 
 
@@ -86,6 +87,10 @@ _lib.csp_minsnap_plan_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_sample_batch.restype = ctypes.c_int
 _lib.csp_minsnap_sample_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+for _n in ("csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch"):
+    getattr(_lib, _n).restype = ctypes.c_int
+    getattr(_lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
+                                  ctypes.c_int32, ctypes.c_void_p]
 _lib.csp_minsnap_kernel_name.restype = ctypes.c_char_p
 _lib.csp_minsnap_kernel_name.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_device_count.restype = ctypes.c_int
@@ -395,3 +400,30 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None):
     _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.ctypes.data, coeffs.ctypes.data, float(sample_distance),
                                          int(capacity), samples.ctypes.data, counts.ctypes.data, stats.ctypes.data, None))
     return samples, counts, stats
+
+
+def _geo(fn, pts, ref):
+    ref = np.ascontiguousarray(ref, dtype=np.float64).reshape(3)
+    if _is_torch(pts):
+        import torch
+        pts = pts.to(torch.float64).contiguous()
+        out = torch.empty_like(pts)
+        st = torch.cuda.current_stream(pts.device).cuda_stream
+        _check(fn(pts.data_ptr(), ref.ctypes.data, out.data_ptr(), pts.shape[0], MEM_DEVICE,
+                  pts.device.index if pts.device.index is not None else -1, ctypes.c_void_p(st)))
+        return out
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    out = np.empty_like(pts)
+    _check(fn(pts.ctypes.data, ref.ctypes.data, out.ctypes.data, pts.shape[0], MEM_HOST, -1, None))
+    return out
+
+
+def wgs84_to_enu_batch(lla, ref):
+    """Batched UavPathPlanner::wgs84ToENU (uavPathPlanning.cpp:1046-1063, :1085-1095).
+    lla [N,3] = (lon_deg, lat_deg, alt_m); ref [3] same convention."""
+    return _geo(_lib.csp_geo_wgs84_to_enu_batch, lla, ref)
+
+
+def enu_to_wgs84_batch(enu, ref):
+    """Batched UavPathPlanner::enuToWGS84 (uavPathPlanning.cpp:1066-1083, :1098-1108)."""
+    return _geo(_lib.csp_geo_enu_to_wgs84_batch, enu, ref)

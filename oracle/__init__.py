@@ -18,8 +18,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     """Compile dense_oracle.c (gcc) if the shared object is missing or stale."""
-    src = os.path.join(_HERE, "dense_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("dense_oracle.c", "geo_oracle.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
@@ -48,6 +48,10 @@ def lib():
             ctypes.c_int, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
             ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.c_long, _dp, _dp, _dp]
         L.csp_oracle_max_threads.restype = ctypes.c_int
+        for name in ("csp_oracle_wgs84_to_enu", "csp_oracle_enu_to_wgs84"):
+            f = getattr(L, name)
+            f.restype = ctypes.c_int
+            f.argtypes = [_dp, _dp, _dp, ctypes.c_long]
         _lib = L
     return _lib
 
@@ -129,3 +133,19 @@ def generate_trajectory(path, order=3, path_weight=0.0, vel_zero_weight=0.0, v_a
 
 def max_threads():
     return int(lib().csp_oracle_max_threads())
+
+
+def wgs84_to_enu(lla, ref):
+    """lla [N,3] = (lon_deg, lat_deg, alt_m), ref [3] -> enu [N,3] (uavPathPlanning.cpp:1046-1063)."""
+    lla, ref = _c(lla).reshape(-1, 3), _c(ref).reshape(3)
+    out = np.zeros_like(lla)
+    lib().csp_oracle_wgs84_to_enu(_p(lla), _p(ref), _p(out), lla.shape[0])
+    return out
+
+
+def enu_to_wgs84(enu, ref):
+    """enu [N,3], ref [3] -> lla [N,3] (uavPathPlanning.cpp:1066-1083)."""
+    enu, ref = _c(enu).reshape(-1, 3), _c(ref).reshape(3)
+    out = np.zeros_like(enu)
+    lib().csp_oracle_enu_to_wgs84(_p(enu), _p(ref), _p(out), enu.shape[0])
+    return out

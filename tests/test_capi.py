@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "csp_minsnap.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(csp_minsnap_[a-z_]+)\s*\(", hdr)))
+    syms = set()
+    for h in ("csp_minsnap.h", "csp_geo.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        syms |= set(re.findall(r"\b(csp_(?:minsnap|geo)_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(syms)
 
 
 def test_every_declared_symbol_is_exported(csp):
