@@ -51,6 +51,52 @@ def cpu_baseline(order, S, wp, tm, budget_s):
                       "(oracle/dense_oracle.c, -O2, OpenMP), %.1f s" % (n, wp.shape[0], dt)}, ref, n
 
 
+def bench_c5(args, csp, dev):
+    """Side benchmark (not the driver's line): BASELINE config C5 -- mixed batch, S ~ U{4..64},
+    order ~ U{3,4,5}, fp32 storage, bucketed by order and sorted by S on the host BEFORE the timed
+    region; one ragged call per order."""
+    trajs = synth.make_ragged(args.batch)
+    buckets = []
+    total_bytes = 0
+    for order in (3, 4, 5):
+        sel = sorted((t for t in trajs if t[0] == order), key=lambda t: len(t[2]))
+        wp = torch.from_numpy(np.concatenate([t[1] for t in sel]).astype(np.float32)).to(dev)
+        tm = torch.from_numpy(np.concatenate([t[2] for t in sel]).astype(np.float32)).to(dev)
+        lens = np.array([len(t[2]) for t in sel])
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev)
+        out = torch.empty((int(lens.sum()), 3, 2 * order), dtype=torch.float32, device=dev)
+        desc = csp.make_desc(order, len(sel), 0, csp.DTYPE_F32, mem_space=csp.MEM_DEVICE, seg_offsets_ptr=off.data_ptr(),
+                             max_segments=int(lens.max()))
+        ws = torch.empty(max(csp.workspace_bytes(desc), 1), dtype=torch.uint8, device=dev)
+        buckets.append((order, wp, tm, off, out, ws, int(lens.max())))
+        total_bytes += sum(synth.algorithmic_bytes(int(n), order, 4) for n in lens)
+
+    # one HIP stream per order bucket: a bucket alone (~22k lanes) cannot fill 1024 SIMDs
+    streams = [torch.cuda.Stream(device=dev) for _ in buckets]
+    main = torch.cuda.current_stream(dev)
+
+    def step():
+        for st_, (order, wp, tm, off, out, ws, smax) in zip(streams, buckets):
+            st_.wait_stream(main)
+            csp.solve_batch(wp, tm, order=order, seg_offsets=off, max_segments=smax, out=out, workspace=ws,
+                            stream=st_.cuda_stream)
+        for st_ in streams:
+            main.wait_stream(st_)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    print(json.dumps({"workload": "C5 mixed ragged, fp32 storage / fp64 arithmetic", "batch": args.batch,
+                      "solves_per_s": args.batch / (ms * 1e-3), "ms_per_step": ms,
+                      "algorithmic_GBps": total_bytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +111,7 @@ def main():
     ap.add_argument("--segment-major", action="store_true",
                     help="experiment: CSP_FLAG_SEGMENT_MAJOR coefficient layout [S][B][3][2o]")
     ap.add_argument("--no-persistent", action="store_true", help="A/B: CSP_FLAG_NO_PERSISTENT")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"], help="c5 = side benchmark of the mixed ragged fp32 path")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the CSP_MEM_HOST boundary (PCIe-inclusive; reported as a side note, never `value`)")
     args = ap.parse_args()
@@ -89,6 +136,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     csp = importlib.import_module("cs-pathplan_amd")
+    if args.workload == "c5":
+        return bench_c5(args, csp, dev)
     B, S, o = args.batch, args.segments, args.order
     wp, tm = synth.make_batch(B, S, config_id=3, offset=rank * B)
     d_wp, d_tm = torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev)

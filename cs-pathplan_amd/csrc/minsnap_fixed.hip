@@ -163,11 +163,6 @@ template <int HS, bool BOTTOM, int TM_STRIDE = FixedLds<HS>::TM_ROW> struct LdsI
     __device__ __forceinline__ double T(int j) const { return l_tm[lane * TM_STRIDE + (BOTTOM ? 2 * HS - 1 - j : j)]; }
     __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * FixedLds<HS>::WP_ROW + (BOTTOM ? 2 * HS - j : j) * 3 + ax]; }
 };
-template <int HS> struct RegInputs {                // pulled into registers once per trajectory
-    double t[HS], p[HS + 1][3];
-    __device__ __forceinline__ double T(int j) const { return t[j]; }
-    __device__ __forceinline__ double P(int j, int ax) const { return p[j][ax]; }
-};
 
 // STASH: the forward sweep keeps the times/waypoints it reads in registers for the backward sweep,
 // so the LDS input image is dead after the exchange barrier; `after_exchange()` runs right after

@@ -16,6 +16,19 @@ namespace csp {
 template <typename IO, typename R>
 __device__ __forceinline__ void load3(const IO *p, R (&v)[3]) { v[0] = R(p[0]); v[1] = R(p[1]); v[2] = R(p[2]); }
 
+// One axis record (M = 2*order values) as 16-byte (f64) or 8-byte (f32) vector stores: record bases
+// are multiples of M*sizeof(IO), i.e. 16*order resp. 8*order bytes.
+template <int M, typename IO> __device__ __forceinline__ void store_row(IO *dst, const IO (&q)[M]) {
+    typedef IO vec2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+        vec2 v;
+        v.x = q[i];
+        v.y = q[i + 1];
+        *reinterpret_cast<vec2 *>(dst + i) = v;
+    }
+}
+
 template <int O, typename IO> struct TrajView {
     const IO *wp;    // [(S+1)][3]
     const IO *tm;    // [S]
@@ -24,11 +37,14 @@ template <int O, typename IO> struct TrajView {
     int S;
 };
 
-// One full solve pass.  path_on selects the penalised system (second pass of :347-469).
+// One full solve pass.  PATH selects the penalised system (second pass of :347-469).
 // Returns status bits; writes coefficients; if dev_out != nullptr also the deviation metric.
-template <int O, typename IO, typename R>
+// Both sweeps are software-pipelined: the inputs (and, backwards, the stored factors) of the NEXT
+// waypoint are requested before the current one is processed, so one lane's chain of dependent
+// global loads overlaps with its arithmetic.
+template <int O, typename IO, typename R, bool PATH>
 __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 1 : 1)][3],
-                          const R (&xS)[(O > 1 ? O - 1 : 1)][3], bool path_on, R pw, R vw,
+                          const R (&xS)[(O > 1 ? O - 1 : 1)][3], R pw, R vw,
                           R *ws, const int *tstar, int64_t B, int64_t b, double *dev_out) {
     constexpr int N = O - 1;
     constexpr int NS = (O > 1) ? O - 1 : 1;
@@ -46,16 +62,21 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) z[r][ax] = x0[r][ax];
         }
-        R Pp[3], Pc[3], Pn[3];
+        R Pp[3], Pc[3], Pn[3], Pnn[3] = {R(0), R(0), R(0)};
         load3<IO, R>(tv.wp, Pp);
         load3<IO, R>(tv.wp + 3, Pc);
+        load3<IO, R>(tv.wp + 6, Pn);
+        R Tn = R(tv.tm[1]), Tnn = R(1);
+        int sn = PATH ? tstar[B] : 0, snn = 0;
         SegBlocks<O, R> left, right;
-        if (path_on) seg_blocks<O, R, true>(R(tv.tm[0]), vw, pw, tstar[0 * B], Pp, Pc, left);
-        else seg_blocks<O, R, false>(R(tv.tm[0]), vw, pw, 0, Pp, Pc, left);
+        seg_blocks<O, R, PATH>(R(tv.tm[0]), vw, pw, PATH ? tstar[0] : 0, Pp, Pc, left);
         for (int k = 1; k < S; ++k) {
-            load3<IO, R>(tv.wp + 3 * (k + 1), Pn);
-            if (path_on) seg_blocks<O, R, true>(R(tv.tm[k]), vw, pw, tstar[(int64_t)k * B], Pc, Pn, right);
-            else seg_blocks<O, R, false>(R(tv.tm[k]), vw, pw, 0, Pc, Pn, right);
+            if (k + 1 < S) {  // prefetch waypoint k+2, time k+1 (and its sample index)
+                load3<IO, R>(tv.wp + 3 * (k + 2), Pnn);
+                Tnn = R(tv.tm[k + 1]);
+                if (PATH) snn = tstar[(int64_t)(k + 1) * B];
+            }
+            seg_blocks<O, R, PATH>(Tn, vw, pw, sn, Pc, Pn, right);
             R A[NS][NS], Bm[NS][NS + 3];
 #pragma unroll
             for (int r = 0; r < N; ++r) {
@@ -73,7 +94,7 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
                     v = fma_<R>(left.ep1[r], Pc[ax], v);
                     v = fma_<R>(right.sp0[r], Pc[ax], v);
                     v = fma_<R>(right.sp1[r], Pn[ax], v);
-                    v += left.fe[r][ax] + right.fs[r][ax];
+                    if (PATH) v += left.fe[r][ax] + right.fs[r][ax];
 #pragma unroll
                     for (int j = 0; j < N; ++j) v = fma_<R>(left.se[j][r], z[j][ax], v);
                     Bm[r][N + ax] = -v;
@@ -90,8 +111,10 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
                 for (int ax = 0; ax < 3; ++ax) { z[r][ax] = Bm[r][N + ax]; wk[(int64_t)(N * N + r * 3 + ax) * B] = z[r][ax]; }
             }
             left = right;
+            Tn = Tnn;
+            sn = snn;
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) { Pp[ax] = Pc[ax]; Pc[ax] = Pn[ax]; }
+            for (int ax = 0; ax < 3; ++ax) { Pp[ax] = Pc[ax]; Pc[ax] = Pn[ax]; Pn[ax] = Pnn[ax]; }
         }
     }
 
@@ -103,7 +126,29 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
         for (int ax = 0; ax < 3; ++ax) xn[r][ax] = (r < N) ? xS[r][ax] : R(0);
     R nanacc = R(0);
     R maxdev = R(0);
+    // state of segment k = S-1 (requested before the loop), then one segment ahead inside it
+    R Tk = R(tv.tm[S - 1]), P0[3], P1[3], wz[WS_ENTRIES > 0 ? WS_ENTRIES : 1];
+    load3<IO, R>(tv.wp + 3 * (S - 1), P0);
+    load3<IO, R>(tv.wp + 3 * S, P1);
+    int sk = (PATH && dev_out) ? tstar[(int64_t)(S - 1) * B] : 0;
+    if (N > 0 && S > 1) {
+        const R *wk = ws + (int64_t)(S - 2) * WS_ENTRIES * B;
+#pragma unroll
+        for (int e = 0; e < WS_ENTRIES; ++e) wz[e] = wk[(int64_t)e * B];
+    }
     for (int k = S - 1; k >= 0; --k) {
+        R Tp = R(1), Pm[3] = {R(0), R(0), R(0)}, wzp[WS_ENTRIES > 0 ? WS_ENTRIES : 1];
+        int sp = 0;
+        if (k >= 1) {  // prefetch segment k-1: its time, start waypoint, sample index and factors
+            Tp = R(tv.tm[k - 1]);
+            load3<IO, R>(tv.wp + 3 * (k - 1), Pm);
+            if (PATH && dev_out) sp = tstar[(int64_t)(k - 1) * B];
+            if (N > 0 && k >= 2) {
+                const R *wk = ws + (int64_t)(k - 2) * WS_ENTRIES * B;
+#pragma unroll
+                for (int e = 0; e < WS_ENTRIES; ++e) wzp[e] = wk[(int64_t)e * B];
+            }
+        }
         R xk[NS][3];
         if (k == 0 || N == 0) {
 #pragma unroll
@@ -111,21 +156,17 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) xk[r][ax] = (r < N) ? x0[r][ax] : R(0);
         } else {
-            const R *wk = ws + (int64_t)(k - 1) * WS_ENTRIES * B;
 #pragma unroll
             for (int r = 0; r < N; ++r)
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
-                    R v = wk[(int64_t)(N * N + r * 3 + ax) * B];
+                    R v = wz[N * N + r * 3 + ax];
 #pragma unroll
-                    for (int c = 0; c < N; ++c) v = fma_<R>(-wk[(int64_t)(r * N + c) * B], xn[c][ax], v);
+                    for (int c = 0; c < N; ++c) v = fma_<R>(-wz[r * N + c], xn[c][ax], v);
                     xk[r][ax] = v;
                 }
         }
-        const R T = R(tv.tm[k]);
-        R P0[3], P1[3];
-        load3<IO, R>(tv.wp + 3 * k, P0);
-        load3<IO, R>(tv.wp + 3 * (k + 1), P1);
+        const R T = Tk;
         R tp[O], ip[M];
         tp[0] = R(1);
 #pragma unroll
@@ -135,7 +176,7 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
 #pragma unroll
         for (int e = 2; e < M; ++e) ip[e] = ip[e - 1] * ip[1];
         R d2 = R(0), len2 = R(0);
-        const R tau = (path_on && dev_out) ? R(tstar[(int64_t)k * B]) * R(0.0625) : R(0);
+        const R tau = (PATH && dev_out) ? R(sk) * R(0.0625) : R(0);
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             R d[M], c[M];
@@ -145,8 +186,10 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
             for (int r = 0; r < N; ++r) { d[r + 1] = xk[r][ax]; d[O + r + 1] = xn[r][ax]; }
             recover_axis<O, R>(d, tp, ip, c);
             IO *dst = tv.co + (int64_t)k * tv.seg_stride + ax * M;
+            IO q[M];
 #pragma unroll
-            for (int i = 0; i < M; ++i) { dst[i] = IO(c[i]); nanacc = fma_<R>(R(dst[i]) , R(0), nanacc); }
+            for (int i = 0; i < M; ++i) { q[i] = IO(c[i]); nanacc = fma_<R>(R(q[i]), R(0), nanacc); }
+            store_row<M, IO>(dst, q);
             if (dev_out) {
                 // deviation at the recorded t* (minimum_snap.cpp:596-617); t* = 0 without path penalty
                 const R ts = T * tau;
@@ -168,6 +211,12 @@ __device__ int solve_pass(const TrajView<O, IO> &tv, const R (&x0)[(O > 1 ? O - 
         for (int r = 0; r < NS; ++r)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
+        Tk = Tp;
+        sk = sp;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { P1[ax] = P0[ax]; P0[ax] = Pm[ax]; }
+#pragma unroll
+        for (int e = 0; e < WS_ENTRIES; ++e) wz[e] = wzp[e];
     }
     if (!(nanacc == R(0))) status |= 1;
     if (dev_out) *dev_out = (double)maxdev;
@@ -208,8 +257,8 @@ __device__ void pick_tstar(const TrajView<O, IO> &tv, int *tstar, int64_t B) {
     }
 }
 
-template <int O, typename IO, typename R>
-__global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
+template <int O, typename IO, typename R, bool PATH>
+__global__ void __launch_bounds__(64) minsnap_generic_kernel(GenericArgs a) {
     constexpr int N = O - 1;
     constexpr int NS = (O > 1) ? O - 1 : 1;
     constexpr int M = 2 * O;
@@ -244,12 +293,12 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
     const R vw = (R)(a.vw_per ? a.vw_per[b] : a.vel_zero_weight);
     int status = 0;
     double dev = 0.0;
-    if (a.path_weight > 0.0) {
-        status |= solve_pass<O, IO, R>(tv, x0, xS, false, R(0), R(0), ws, tstar, a.B, b, nullptr);
+    if (PATH) {
+        status |= solve_pass<O, IO, R, false>(tv, x0, xS, R(0), R(0), ws, tstar, a.B, b, nullptr);
         pick_tstar<O, IO, R>(tv, tstar, a.B);
-        status = solve_pass<O, IO, R>(tv, x0, xS, true, pw, vw, ws, tstar, a.B, b, &dev);
+        status = solve_pass<O, IO, R, true>(tv, x0, xS, pw, vw, ws, tstar, a.B, b, &dev);
     } else {
-        status = solve_pass<O, IO, R>(tv, x0, xS, false, R(0), vw, ws, tstar, a.B, b, a.max_dev ? &dev : nullptr);
+        status = solve_pass<O, IO, R, false>(tv, x0, xS, R(0), vw, ws, tstar, a.B, b, a.max_dev ? &dev : nullptr);
     }
     if (a.status) a.status[b] = status;
     if (a.max_dev) a.max_dev[b] = dev;
@@ -257,9 +306,10 @@ __global__ void __launch_bounds__(256) minsnap_generic_kernel(GenericArgs a) {
 
 template <int O, typename IO, typename R> static hipError_t launch_o(const GenericArgs &a, hipStream_t st) {
     if (a.B == 0) return hipSuccess;
-    const int threads = 256;
+    const int threads = 64;  // one wave per workgroup: small ragged buckets still cover every CU
     const int64_t blocks = (a.B + threads - 1) / threads;
-    hipLaunchKernelGGL((minsnap_generic_kernel<O, IO, R>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    if (a.path_weight > 0.0) hipLaunchKernelGGL((minsnap_generic_kernel<O, IO, R, true>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL((minsnap_generic_kernel<O, IO, R, false>), dim3((unsigned)blocks), dim3(threads), 0, st, a);
     return hipGetLastError();
 }
 
