@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
     "csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch",
+    "csp_alt_workspace_bytes", "csp_alt_optimize_heights_batch", "csp_alt_global_smooth_batch",
 )
 
 
@@ -427,3 +428,53 @@ def wgs84_to_enu_batch(lla, ref):
 def enu_to_wgs84_batch(enu, ref):
     """Batched UavPathPlanner::enuToWGS84 (uavPathPlanning.cpp:1066-1083, :1098-1108)."""
     return _geo(_lib.csp_geo_enu_to_wgs84_batch, enu, ref)
+
+
+class AltParams(ctypes.Structure):
+    """Mirror of `csp_alt_params` (include/csp_alt.h; reference AltitudeParams, uavPathPlanning.hpp:415-421)."""
+    _fields_ = [("lambda_smooth", ctypes.c_double), ("lambda_follow", ctypes.c_double),
+                ("safe_distance", ctypes.c_double), ("max_climb_rate", ctypes.c_double)]
+
+
+_lib.csp_alt_workspace_bytes.restype = ctypes.c_size_t
+_lib.csp_alt_workspace_bytes.argtypes = [ctypes.c_int64]
+_lib.csp_alt_optimize_heights_batch.restype = ctypes.c_int
+_lib.csp_alt_optimize_heights_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.POINTER(AltParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p]
+_lib.csp_alt_global_smooth_batch.restype = ctypes.c_int
+_lib.csp_alt_global_smooth_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.POINTER(AltParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p]
+
+
+def _alt_params(lambda_smooth, lambda_follow, safe_distance, max_climb_rate):
+    return AltParams(float(lambda_smooth), float(lambda_follow), float(safe_distance), float(max_climb_rate))
+
+
+def alt_optimize_heights_batch(xyz, elev, offsets, lambda_smooth=1.0, lambda_follow=0.0, safe_distance=50.0,
+                               max_climb_rate=2.0):
+    """Batched UavPathPlanner::optimizeHeights (uavPathPlanning.cpp:1575-1713).  Host (numpy) arrays:
+    xyz [total,3], elev [total] (NaN = no terrain sample), offsets [B+1].  Returns z [total]."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    elev = np.ascontiguousarray(elev, dtype=np.float64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    out = np.empty(xyz.shape[0])
+    p = _alt_params(lambda_smooth, lambda_follow, safe_distance, max_climb_rate)
+    _check(_lib.csp_alt_optimize_heights_batch(xyz.ctypes.data, elev.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
+                                               ctypes.byref(p), out.ctypes.data, None, 0, MEM_HOST, -1, None))
+    return out
+
+
+def alt_global_smooth_batch(input_z, xyz, offsets, lambda_smooth=1.0, max_climb_rate=2.0):
+    """Batched UavPathPlanner::optimizeHeightsGlobalSmooth (uavPathPlanning.cpp:1715-1827).
+    Returns (z [total], solves [B])."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    input_z = np.ascontiguousarray(input_z, dtype=np.float64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    out = np.empty(xyz.shape[0])
+    solves = np.empty(offsets.shape[0] - 1, dtype=np.int32)
+    p = _alt_params(lambda_smooth, 0.0, 0.0, max_climb_rate)
+    _check(_lib.csp_alt_global_smooth_batch(input_z.ctypes.data, xyz.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
+                                            ctypes.byref(p), out.ctypes.data, solves.ctypes.data, None, 0, MEM_HOST, -1, None))
+    return out, solves

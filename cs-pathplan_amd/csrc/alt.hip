@@ -1,0 +1,184 @@
+// alt.hip -- banded LDL^T for the altitude optimiser's pentadiagonal SPD systems
+// (reference: uavPathPlanning.cpp:1575-1827, the only Eigen::SimplicialLDLT call sites).
+// One lane per problem: the factorisation of a pentadiagonal matrix is a two-term recurrence, so a
+// problem is sequential in its sample index and parallelism comes from the batch.  The matrix is
+// never stored: row i's diagonal and two sub-diagonal entries are rebuilt from the neighbouring
+// samples while sweeping; per row the sweep keeps (l1, l2, w) in the workspace for the backward pass.
+// Not tuned (row N4): a single long problem would want a wave-cooperative cyclic reduction.
+#include "../../include/csp_alt.h"
+#include "../../include/csp_minsnap.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+
+namespace {
+
+struct AltArgs {
+    const double *a, *xyz;       // a = elev (optimize) or input_z (global smooth)
+    const int64_t *off;
+    double *out;
+    int32_t *solves;
+    double *ws;                  // [total][4]: l1, l2, w, active flag
+    int64_t B;
+    csp_alt_params p;
+};
+
+// climb-rate weight of edge (i, i+1) (uavPathPlanning.cpp:1641-1656)
+__device__ __forceinline__ double edge_w(const double *xyz, int64_t i, double rate) {
+    if (!(rate > 0.0)) return 0.0;
+    const double dist = hypot(xyz[(i + 1) * 3] - xyz[i * 3], xyz[(i + 1) * 3 + 1] - xyz[i * 3 + 1]);
+    if (dist <= 1e-9) return 0.0;
+    const double denom = dist * rate;
+    if (denom <= 1e-12) return 0.0;
+    return 1.0 / (denom * denom);
+}
+
+// Row i of lambda*L^T L + climb-rate terms: diagonal, H[i][i-1], H[i][i-2].
+__device__ __forceinline__ void band_row(const double *xyz, int64_t n, int64_t i, double s, double rate, double w_prev,
+                                         double w_next, double &diag, double &e, double &f) {
+    diag = 0.0; e = 0.0; f = 0.0;
+    if (n >= 3 && s > 0.0) {
+        const bool in_m = (i - 1 >= 1 && i - 1 <= n - 2), in_0 = (i >= 1 && i <= n - 2), in_p = (i + 1 >= 1 && i + 1 <= n - 2);
+        diag += (in_p ? s : 0.0) + (in_0 ? 4.0 * s : 0.0) + (in_m ? s : 0.0);
+        e += (in_0 ? -2.0 * s : 0.0) + (in_m ? -2.0 * s : 0.0);   // entries (t, t-1) of t = i and (t+1, t) of t = i-1
+        f += in_m ? s : 0.0;                                        // entry (t+1, t-1) of t = i-1
+    }
+    diag += w_prev + w_next;
+    e += -w_prev;
+}
+
+// One banded LDL^T solve.  extra_d(i) / rhs(i) supply the problem-specific diagonal and right side.
+template <class D, class Rh>
+__device__ __forceinline__ void banded_solve(const double *xyz, double *ws, int64_t n, double s, double rate, D extra_d, Rh rhs) {
+    double d1 = 1.0, d2 = 1.0, l1p = 0.0, y1 = 0.0, y2 = 0.0;   // d_{i-1}, d_{i-2}, l1_{i-1}, y_{i-1}, y_{i-2}
+    double w_prev = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double w_next = (i + 1 < n) ? edge_w(xyz, i, rate) : 0.0;
+        double diag, e, f;
+        band_row(xyz, n, i, s, rate, w_prev, w_next, diag, e, f);
+        diag += extra_d(i) + 1e-8;                               // tiny regularisation (:1659-1661)
+        const double l2 = (i >= 2) ? f / d2 : 0.0;
+        const double l1 = (i >= 1) ? (e - l2 * l1p * d2) / d1 : 0.0;
+        const double d = diag - l1 * l1 * d1 - l2 * l2 * d2;
+        const double y = rhs(i) - l1 * y1 - l2 * y2;
+        ws[i * 4 + 0] = l1;
+        ws[i * 4 + 1] = l2;
+        ws[i * 4 + 2] = y / d;
+        d2 = d1; d1 = d; l1p = l1; y2 = y1; y1 = y; w_prev = w_next;
+    }
+    double z1 = 0.0, z2 = 0.0, l1n = 0.0, l2n = 0.0, l2nn = 0.0;  // z_{i+1}, z_{i+2}, l1_{i+1}, l2_{i+1}, l2_{i+2}
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const double z = ws[i * 4 + 2] - l1n * z1 - l2nn * z2;
+        const double l1 = ws[i * 4 + 0], l2 = ws[i * 4 + 1];
+        ws[i * 4 + 2] = z;
+        z2 = z1; z1 = z; l2nn = l2n; l1n = l1; l2n = l2;
+    }
+}
+
+__global__ void __launch_bounds__(64) alt_optimize_kernel(AltArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) return;
+    const double *xyz = a.xyz + o * 3, *elev = a.a + o;
+    double *ws = a.ws + o * 4, *out = a.out + o;
+    const csp_alt_params p = a.p;
+    banded_solve(xyz, ws, n, p.lambda_smooth, p.max_climb_rate,
+                 [&](int64_t i) { return isnan(elev[i]) ? 0.0 : p.lambda_follow; },
+                 [&](int64_t i) {
+                     if (isnan(elev[i])) return 0.0;
+                     const double safe_h = elev[i] + p.safe_distance;   // follow terrain + clearance, never pull down (:1633-1639)
+                     return p.lambda_follow * fmax(xyz[i * 3 + 2], safe_h);
+                 });
+    for (int64_t i = 0; i < n; ++i) {                            // post-check z >= elev + safe_distance (:1689-1710)
+        double z = ws[i * 4 + 2];
+        if (!isnan(elev[i]) && z < elev[i] + p.safe_distance) z = elev[i] + p.safe_distance;
+        out[i] = z;
+    }
+}
+
+__global__ void __launch_bounds__(64) alt_global_smooth_kernel(AltArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) { if (a.solves) a.solves[b] = 0; return; }
+    const double *xyz = a.xyz + o * 3, *zin = a.a + o;
+    double *ws = a.ws + o * 4, *out = a.out + o;
+    const csp_alt_params p = a.p;
+    for (int64_t i = 0; i < n; ++i) ws[i * 4 + 3] = 0.0;          // active set empty
+    int solves = 0;
+    for (int iter = 0; iter < 10; ++iter) {
+        banded_solve(xyz, ws, n, p.lambda_smooth, p.max_climb_rate,
+                     [&](int64_t i) { return (i == 0 || i == n - 1) ? 1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0)
+                                                                    : (ws[i * 4 + 3] != 0.0 ? 1e8 : 0.0); },
+                     [&](int64_t i) { return (i == 0 || i == n - 1) ? (1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0)) * zin[i]
+                                                                    : (ws[i * 4 + 3] != 0.0 ? 1e8 * zin[i] : 0.0); });
+        ++solves;
+        bool violation = false;
+        for (int64_t i = 0; i < n; ++i)
+            if (ws[i * 4 + 2] < zin[i] - 1e-3 && ws[i * 4 + 3] == 0.0) { ws[i * 4 + 3] = 1.0; violation = true; }
+        if (!violation) break;
+    }
+    for (int64_t i = 0; i < n; ++i) out[i] = fmax(ws[i * 4 + 2], zin[i]);
+    if (a.solves) a.solves[b] = solves;
+}
+
+template <typename K>
+int run(K kernel, const double *a0, const double *xyz, const int64_t *offsets, int64_t batch, const csp_alt_params *p,
+        double *out, int32_t *solves, void *workspace, size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *stream) {
+    if (batch < 0 || !p || (batch > 0 && (!a0 || !xyz || !offsets || !out))) return CSP_ERR_INVALID_ARG;
+    if (batch == 0) return CSP_OK;
+    if (csp_minsnap_device_count() < 1) return CSP_ERR_NO_DEVICE;
+    if (device_id >= 0 && hipSetDevice(device_id) != hipSuccess) return CSP_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    AltArgs a;
+    a.B = batch; a.p = *p;
+    const unsigned blocks = (unsigned)((batch + 63) / 64);
+    if (mem_space == CSP_MEM_DEVICE) {
+        int64_t total = 0;
+        if (hipMemcpyAsync(&total, offsets + batch, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return CSP_ERR_HIP;
+        if (!workspace || workspace_bytes < csp_alt_workspace_bytes(total)) return CSP_ERR_WORKSPACE;
+        a.a = a0; a.xyz = xyz; a.off = offsets; a.out = out; a.solves = solves; a.ws = (double *)workspace;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
+        return hipGetLastError() == hipSuccess ? CSP_OK : CSP_ERR_HIP;
+    }
+    const int64_t total = offsets[batch];
+    double *d_a = nullptr, *d_xyz = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    int64_t *d_off = nullptr;
+    int32_t *d_sv = nullptr;
+    int rc = CSP_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) rc = CSP_ERR_HIP; return e == hipSuccess; };
+    if (ok(hipMalloc(&d_a, (size_t)total * 8 + 8)) && ok(hipMalloc(&d_xyz, (size_t)total * 24 + 8)) && ok(hipMalloc(&d_out, (size_t)total * 8 + 8)) &&
+        ok(hipMalloc(&d_ws, csp_alt_workspace_bytes(total) + 8)) && ok(hipMalloc(&d_off, (size_t)(batch + 1) * 8)) &&
+        ok(hipMalloc(&d_sv, (size_t)batch * 4)) &&
+        ok(hipMemcpyAsync(d_a, a0, (size_t)total * 8, hipMemcpyHostToDevice, st)) &&
+        ok(hipMemcpyAsync(d_xyz, xyz, (size_t)total * 24, hipMemcpyHostToDevice, st)) &&
+        ok(hipMemcpyAsync(d_off, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, st))) {
+        a.a = d_a; a.xyz = d_xyz; a.off = d_off; a.out = d_out; a.solves = d_sv; a.ws = d_ws;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
+        ok(hipGetLastError());
+        ok(hipMemcpyAsync(out, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+        if (solves) ok(hipMemcpyAsync(solves, d_sv, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+        ok(hipStreamSynchronize(st));
+    }
+    (void)hipFree(d_a); (void)hipFree(d_xyz); (void)hipFree(d_out); (void)hipFree(d_ws); (void)hipFree(d_off); (void)hipFree(d_sv);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" size_t csp_alt_workspace_bytes(int64_t total_points) { return total_points > 0 ? (size_t)total_points * 32 : 0; }
+
+extern "C" int csp_alt_optimize_heights_batch(const double *xyz, const double *elev, const int64_t *offsets, int64_t batch,
+                                              const csp_alt_params *params, double *out_z, void *workspace,
+                                              size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
+    return run(alt_optimize_kernel, elev, xyz, offsets, batch, params, out_z, nullptr, workspace, workspace_bytes, mem_space,
+               device_id, hip_stream);
+}
+
+extern "C" int csp_alt_global_smooth_batch(const double *input_z, const double *xyz, const int64_t *offsets, int64_t batch,
+                                           const csp_alt_params *params, double *out_z, int32_t *solves, void *workspace,
+                                           size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
+    return run(alt_global_smooth_kernel, input_z, xyz, offsets, batch, params, out_z, solves, workspace, workspace_bytes,
+               mem_space, device_id, hip_stream);
+}

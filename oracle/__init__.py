@@ -18,7 +18,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     """Compile dense_oracle.c (gcc) if the shared object is missing or stale."""
-    srcs = [os.path.join(_HERE, f) for f in ("dense_oracle.c", "geo_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("dense_oracle.c", "geo_oracle.c", "alt_oracle.c", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -52,6 +52,10 @@ def lib():
             f = getattr(L, name)
             f.restype = ctypes.c_int
             f.argtypes = [_dp, _dp, _dp, ctypes.c_long]
+        L.csp_oracle_alt_optimize.restype = ctypes.c_int
+        L.csp_oracle_alt_optimize.argtypes = [ctypes.c_int, _dp, _dp] + [ctypes.c_double] * 4 + [_dp]
+        L.csp_oracle_alt_global_smooth.restype = ctypes.c_int
+        L.csp_oracle_alt_global_smooth.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp]
         _lib = L
     return _lib
 
@@ -149,3 +153,24 @@ def enu_to_wgs84(enu, ref):
     out = np.zeros_like(enu)
     lib().csp_oracle_enu_to_wgs84(_p(enu), _p(ref), _p(out), enu.shape[0])
     return out
+
+
+def alt_optimize(xyz, elev, lambda_smooth=1.0, lambda_follow=0.0, safe_distance=50.0, max_climb_rate=2.0):
+    """optimizeHeights (uavPathPlanning.cpp:1575-1713); elev NaN = no terrain sample."""
+    xyz, elev = _c(xyz).reshape(-1, 3), _c(elev)
+    out = np.zeros(xyz.shape[0])
+    rc = lib().csp_oracle_alt_optimize(xyz.shape[0], _p(xyz), _p(elev), lambda_smooth, lambda_follow, safe_distance,
+                                       max_climb_rate, _p(out))
+    if rc:
+        raise ValueError("alt_optimize failed")
+    return out
+
+
+def alt_global_smooth(input_z, xyz, lambda_smooth=1.0, max_climb_rate=2.0):
+    """optimizeHeightsGlobalSmooth (uavPathPlanning.cpp:1715-1827).  Returns (z, number of solves)."""
+    input_z, xyz = _c(input_z), _c(xyz).reshape(-1, 3)
+    out = np.zeros(xyz.shape[0])
+    n = lib().csp_oracle_alt_global_smooth(xyz.shape[0], _p(input_z), _p(xyz), lambda_smooth, max_climb_rate, _p(out))
+    if n < 0:
+        raise ValueError("alt_global_smooth failed")
+    return out, n

@@ -1,0 +1,110 @@
+"""Row N4: the altitude optimiser's two pentadiagonal SPD solves (the reference's only
+Eigen::SimplicialLDLT sites, uavPathPlanning.cpp:1575-1827).  PARITY UNPINNED (no Eigen, no goldens):
+the C oracle (dense Cholesky) is pinned against an independent numpy restatement here; the HIP
+kernels (banded LDL^T) are compared with the oracle on the GPU box."""
+import numpy as np
+import pytest
+
+import oracle
+
+
+def _problem(rng, n, with_gaps=True):
+    xy = np.cumsum(rng.uniform(20, 60, size=(n, 2)), axis=0)
+    z = 100 + np.cumsum(rng.normal(0, 8, n))
+    elev = 80 + 10 * np.sin(np.arange(n) / 5.0) + rng.normal(0, 2, n)
+    if with_gaps:
+        elev[rng.integers(0, n, max(1, n // 7))] = np.nan
+    return np.column_stack([xy, z]), elev
+
+
+def _np_hessian(n, xyz, ls, mcr):
+    H = np.zeros((n, n))
+    if n >= 3 and ls > 0:
+        for i in range(1, n - 1):
+            c = np.array([1.0, -2.0, 1.0])
+            H[i - 1:i + 2, i - 1:i + 2] += ls * np.outer(c, c)
+    if mcr > 0:
+        for i in range(n - 1):
+            d = np.hypot(*(xyz[i + 1, :2] - xyz[i, :2]))
+            if d <= 1e-9 or d * mcr <= 1e-12:
+                continue
+            w = 1.0 / (d * mcr) ** 2
+            H[i, i] += w; H[i + 1, i + 1] += w; H[i, i + 1] -= w; H[i + 1, i] -= w
+    return H
+
+
+def _np_optimize(xyz, elev, ls, lf, sd, mcr):
+    n = len(elev)
+    H = _np_hessian(n, xyz, ls, mcr)
+    b = np.zeros(n)
+    for i in range(n):
+        if not np.isnan(elev[i]):
+            H[i, i] += lf
+            b[i] += lf * max(xyz[i, 2], elev[i] + sd)
+        H[i, i] += 1e-8
+    z = np.linalg.solve(H, b)
+    for i in range(n):
+        if not np.isnan(elev[i]):
+            z[i] = max(z[i], elev[i] + sd)
+    return z
+
+
+def _np_global(zin, xyz, ls, mcr):
+    n = len(zin)
+    active = np.zeros(n, bool)
+    z = zin.copy()
+    solves = 0
+    for _ in range(10):
+        H = _np_hessian(n, xyz, ls, mcr)
+        b = np.zeros(n)
+        H[0, 0] += 1e10; b[0] += 1e10 * zin[0]
+        H[-1, -1] += 1e10; b[-1] += 1e10 * zin[-1]
+        for i in range(1, n - 1):
+            if active[i]:
+                H[i, i] += 1e8; b[i] += 1e8 * zin[i]
+        H[np.arange(n), np.arange(n)] += 1e-8
+        z = np.linalg.solve(H, b)
+        solves += 1
+        new = (z < zin - 1e-3) & ~active
+        active |= new
+        if not new.any():
+            break
+    return np.maximum(z, zin), solves
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 120])
+def test_oracle_matches_numpy(n):
+    rng = np.random.default_rng(n)
+    xyz, elev = _problem(rng, n, with_gaps=n > 3)
+    for (ls, lf, sd, mcr) in [(1.0, 0.5, 50.0, 2.0), (3.0, 2.0, 30.0, 0.5), (1.0, 0.0, 50.0, 2.0)]:
+        if lf == 0.0 and n < 3:
+            continue
+        z = oracle.alt_optimize(xyz, elev, ls, lf, sd, mcr)
+        assert np.allclose(z, _np_optimize(xyz, elev, ls, lf, sd, mcr), rtol=1e-7, atol=1e-6)
+    zin = xyz[:, 2] + 5.0
+    g, k = oracle.alt_global_smooth(zin, xyz, 1.0, 2.0)
+    g2, k2 = _np_global(zin, xyz, 1.0, 2.0)
+    assert k == k2
+    assert np.allclose(g, g2, rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_banded_ldlt_matches_oracle(csp):
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 5, 40, 333, 64, 7, 900]
+    probs = [_problem(rng, n, with_gaps=n > 3) for n in sizes]
+    xyz = np.concatenate([p[0] for p in probs])
+    elev = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    for (ls, lf, sd, mcr) in [(1.0, 0.5, 50.0, 2.0), (3.0, 2.0, 30.0, 0.5)]:
+        z = csp.alt_optimize_heights_batch(xyz, elev, off, ls, lf, sd, mcr)
+        for i, n in enumerate(sizes):
+            ref = oracle.alt_optimize(probs[i][0], probs[i][1], ls, lf, sd, mcr)
+            assert np.allclose(z[off[i]:off[i + 1]], ref, rtol=1e-8, atol=1e-6), (n, ls)
+    zin = xyz[:, 2] + rng.uniform(0, 10, len(xyz))
+    g, solves = csp.alt_global_smooth_batch(zin, xyz, off, 1.0, 2.0)
+    for i, n in enumerate(sizes):
+        ref, k = oracle.alt_global_smooth(zin[off[i]:off[i + 1]], probs[i][0], 1.0, 2.0)
+        assert solves[i] == k, (n, solves[i], k)
+        assert np.allclose(g[off[i]:off[i + 1]], ref, rtol=1e-6, atol=1e-4), n
+        assert (g[off[i]:off[i + 1]] >= zin[off[i]:off[i + 1]]).all()
