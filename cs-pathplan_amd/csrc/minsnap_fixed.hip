@@ -571,7 +571,12 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
                                                      const double *l_tm, double *stage, double *partner_stage,
                                                      SlicePrefetch<HS> pf) {
     constexpr int S = 2 * HS;
-    constexpr int STORES_PER_SLICE = 13 * HS;  // per wave; all younger than that slice's prefetch
+    // Vector-memory operations a wave issues AFTER a slice's prefetch and before the next top-of-loop
+    // wait: its store bursts.  Must not be over-estimated (the counted wait below relies on at least
+    // this many younger operations existing).  Paired records: 8 + 16 stores per pair; single
+    // records (segment-major layout, or the straddling middle pair of an odd half): 13 each.
+    constexpr int PAIRS = SEGMAJ ? 0 : HS / 2;
+    constexpr int STORES_PER_SLICE = PAIRS * 24 + (HS - 2 * PAIRS) * 13;
     bool first = true;
     for (int64_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
         // the prefetch of this slice is older than every store of the previous slice, so waiting for

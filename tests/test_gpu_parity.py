@@ -99,6 +99,28 @@ def test_fixed_kernel_every_bucket_and_ragged_tails(csp, oracle_mod, S):
             assert synth.rel_err(r.coeffs[b].reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, (S, B, b)
 
 
+@pytest.mark.parametrize("S", [2, 4, 6, 8, 16])
+def test_persistent_workgroups_walk_several_slices(csp, oracle_mod, S):
+    """B > 2*CUs*64 makes every persistent workgroup solve more than one 64-trajectory slice, so the
+    LDS-DMA prefetch, its counted wait and the tile/exchange reuse across slices are exercised for
+    every store-burst shape (paired, single, straddling middle pair at S=6)."""
+    import torch
+    B = 512 * 64 * 2 + 64 * 37 + 5
+    wp, tm = synth.make_batch(B, S, config_id=50 + S)
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    for seg_major in (False, True):
+        a = csp.solve_batch(d_wp, d_tm, order=4, segment_major=seg_major).coeffs
+        g = csp.solve_batch(d_wp, d_tm, order=4, force_generic=True, segment_major=seg_major).coeffs
+        torch.cuda.synchronize()
+        a, g = a.cpu().numpy(), g.cpu().numpy()
+        if seg_major:
+            a, g = np.transpose(a, (1, 0, 2, 3)), np.transpose(g, (1, 0, 2, 3))
+        assert synth.rel_err(a, g) < 1e-9, (S, seg_major)
+    idx = np.array([0, 63, 64, 32768, 40000, B - 6, B - 1])
+    ref, _ = oracle_mod.solve_batch(4, wp[idx], tm[idx])
+    assert synth.rel_err(a[idx], ref) < TOL_WELL
+
+
 def test_status_flags_bad_trajectories_only(csp):
     wp, tm = synth.make_batch(130, 16, config_id=3)
     tm[5, 3] = 0.0        # zero-length segment time -> 1/T = inf -> non-finite coefficients
