@@ -12,12 +12,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcsp_minsnap.so")
-SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_fixed.hip", "minsnap_timealloc.hip", "minsnap_plan.hip", "geo.hip", "alt.hip"]
-HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_tables.h",
+SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_fixed.hip", "minsnap_fixed_o2.hip", "minsnap_fixed_o3.hip",
+           "minsnap_fixed_o4.hip", "minsnap_fixed_o5.hip", "minsnap_timealloc.hip", "minsnap_plan.hip", "geo.hip", "alt.hip"]
+HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_tables.h", "minsnap_fixed_impl.h",
            os.path.join("..", "..", "include", "csp_minsnap.h"), os.path.join("..", "..", "include", "csp_geo.h"), os.path.join("..", "..", "include", "csp_alt.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-         "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+OBJDIR = os.path.join(HERE, "build")
 
 
 def _stale():
@@ -27,20 +28,47 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _compile_all(extra, tag, verbose):
+    """One hipcc -c per translation unit, in parallel (the per-order kernel files dominate), then link."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, "%s%s.o" % (os.path.splitext(src)[0], tag))
+        srcp = os.path.join(CSRC, src)
+        deps = [srcp] + [os.path.join(CSRC, h) for h in HEADERS]
+        if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            jobs.append((None, obj))
+        else:
+            jobs.append(([HIPCC] + FLAGS + extra + ["-c", srcp, "-o", obj], obj))
+
+    def run(job):
+        cmd, obj = job
+        if cmd:
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        return list(ex.map(run, jobs))
+
+
 def build(force=False, verbose=False, stamps=False):
     """stamps=True builds the DIAGNOSTIC library libcsp_minsnap_stamps.so (in-kernel s_memtime
     stamps, never timed, never shipped) next to the product library."""
     if stamps:
         out = os.path.join(HERE, "libcsp_minsnap_stamps.so")
-        cmd = [HIPCC] + FLAGS + ["-DCSP_STAMPS", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
-        subprocess.check_call(cmd)
+        objs = _compile_all(["-DCSP_STAMPS"], "_stamps", verbose)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
         return out
+    if force and os.path.isdir(OBJDIR):
+        for f in os.listdir(OBJDIR):
+            if f.endswith(".o") and not f.endswith("_stamps.o"):
+                os.remove(os.path.join(OBJDIR, f))
     if not (force or _stale()):
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objs = _compile_all([], "", verbose)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -62,7 +62,7 @@ int validate(const csp_minsnap_desc *d, Shape &s) {
 
 bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
     if (d->flags & CSP_FLAG_FORCE_GENERIC) return false;
-    return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged);
+    return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged, (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }
 
 size_t ws_bytes(const csp_minsnap_desc *d, const Shape &s, size_t *tstar_off) {
@@ -165,7 +165,7 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
     static thread_local char name[64];
     Shape s;
     if (validate(desc, s) != CSP_OK) return nullptr;
-    if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.S);
+    if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.order, s.S);
     std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order,
                   !s.f32 ? "f64" : ((desc->flags & CSP_FLAG_F32_ARITH) ? "f32" : "f32io_f64"), s.ragged ? "_ragged" : "");
     return name;

@@ -1,0 +1,695 @@
+// minsnap_fixed_impl.h -- register-resident kernels for the uniform fixed-size buckets
+// (fp64, derivative order O in 2..5, even segment count S = 2*HS, no path penalty).
+// Instantiated once per order by minsnap_fixed_o<O>.hip; the dispatcher is minsnap_fixed.hip.
+//
+// Mapping: a trajectory is split at its middle waypoint between two WAVES of one
+// workgroup.  Wave 0 ("top") eliminates interior waypoints 1..S/2-1 downwards, wave 1
+// ("bottom") runs the very same code on the time-reversed second half (reversed waypoint order,
+// odd derivatives negated), i.e. a twisted block-LDL^T factorisation of the block-tridiagonal
+// R_PP (minimum_snap.cpp:564-566).  Lane l of both waves owns trajectory 64*slice+l, so every
+// value a lane needs later (W_k = S_k^-1 C_k and z_k = S_k^-1 y_k) stays in ITS registers --
+// nothing is spilled to memory between the forward and the backward sweep.  The two halves meet
+// once, through n(n+1)/2 + 3n doubles per lane in LDS (n = O-1): each side's Schur carry onto the
+// middle waypoint.  The roles are wave-uniform, so the only divergence is a scalar branch.
+//
+// Algorithmic HBM traffic per trajectory: 8*(3(S+1)+S) bytes in, 8*6*O*S bytes out
+// (O=4, S=16: 536 + 3072 = 3608 B); no workspace.
+#pragma once
+#include "minsnap_device.h"
+#include "minsnap_launch.h"
+
+#include <type_traits>
+
+#ifdef CSP_STAMPS
+// Diagnostic build only (python cs-pathplan_amd/build.py --stamps): per-wave s_memtime stamps
+// written to a buffer nothing else reads.  The shipped library contains none of this.
+static __device__ unsigned long long csp_g_stamps[8192 * 8];  // one copy per translation unit; tools read order 4's
+#define CSP_STAMP(slot)                                                                     \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                   \
+            csp_g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;          \
+    } while (0)
+#define CSP_STAMP_RT(slot)                                                                  \
+    do {                                                                                    \
+        unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                           \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                   \
+            csp_g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;          \
+    } while (0)
+#else
+#define CSP_STAMP(slot) do { } while (0)
+#define CSP_STAMP_RT(slot) do { } while (0)
+#endif
+
+namespace csp {
+namespace fixedk {
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for every
+// outstanding global store (vmcnt(0)); the persistent kernel keeps stores and the next
+// slice's LDS-DMA in flight across its barriers.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Scaled per-segment constants (free derivatives r = 1..O-1 -> index r-1).
+// ee[r][c] = (-1)^(r+c) ss[r][c] and Qt[.][end pos] = -Qt[.][start pos] (checked in
+// tests/test_tables.py), so only ss, se and the two start-position columns are formed.
+template <int O> struct Seg {
+    static constexpr int N = O - 1;
+    double ss[N][N];  // symmetric; full storage keeps the unrolled code simple
+    double se[N][N];
+    double sp[N];     // Qt[start r][start pos]
+    double ep[N];     // Qt[end r][start pos]
+};
+
+template <int O> __device__ __forceinline__ void seg_make(double T, double vw, Seg<O> &s) {
+    constexpr int N = O - 1, M = 2 * O;
+    double ip[M];  // ip[e] = T^-e;  Qt(T)[a][b] = Qt1[a][b] * T^(1 - 2o + d_a + d_b)
+    ip[0] = 1.0;
+    ip[1] = fast_rcp(T);
+#pragma unroll
+    for (int e = 2; e < M; ++e) ip[e] = ip[e - 1] * ip[1];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            s.ss[r][c] = Tab<O>::QT(r + 1, c + 1) * ip[M - 3 - r - c];
+            s.se[r][c] = Tab<O>::QT(r + 1, O + c + 1) * ip[M - 3 - r - c];
+        }
+        s.sp[r] = Tab<O>::QT(r + 1, 0) * ip[M - 2 - r];
+        s.ep[r] = Tab<O>::QT(O + r + 1, 0) * ip[M - 2 - r];
+    }
+    s.ss[0][0] += vw;  // zero-velocity penalty: +w on the velocity diagonal (minimum_snap.cpp:473-509)
+}
+
+template <int O> __device__ __forceinline__ double ee_of(const Seg<O> &s, int r, int c) {
+    return ((r + c) & 1) ? -s.ss[r][c] : s.ss[r][c];
+}
+
+// X = S^-1 B for a small symmetric positive definite S (lower triangle read), NR right-hand
+// sides.  n <= 3: cofactor inverse with ONE Newton-refined reciprocal (short dependency chain);
+// n = 4: LDL^T.  Returns false when a leading minor / pivot is not positive.
+template <int N, int NR> struct SmallSpd;
+template <int NR> struct SmallSpd<1, NR> {
+    __device__ static __forceinline__ bool solve(double (&S)[1][1], double (&B)[1][NR]) {
+        const double r = fast_rcp(S[0][0]);
+#pragma unroll
+        for (int c = 0; c < NR; ++c) B[0][c] *= r;
+        return S[0][0] > 0.0;
+    }
+};
+template <int NR> struct SmallSpd<2, NR> {
+    __device__ static __forceinline__ bool solve(double (&S)[2][2], double (&B)[2][NR]) {
+        const double a = S[0][0], b = S[1][0], c = S[1][1];
+        const double det = __builtin_fma(a, c, -b * b);
+        const double rd = fast_rcp(det);
+        const double i00 = c * rd, i10 = -b * rd, i11 = a * rd;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const double x0 = B[0][k], x1 = B[1][k];
+            B[0][k] = __builtin_fma(i10, x1, i00 * x0);
+            B[1][k] = __builtin_fma(i11, x1, i10 * x0);
+        }
+        return (a > 0.0) && (det > 0.0);
+    }
+};
+template <int NR> struct SmallSpd<3, NR> {
+    __device__ static __forceinline__ bool solve(double (&S)[3][3], double (&B)[3][NR]) {
+        const double a = S[0][0], b = S[1][0], c = S[1][1], d = S[2][0], e = S[2][1], f = S[2][2];
+        const double c00 = __builtin_fma(c, f, -e * e);
+        const double c10 = __builtin_fma(d, e, -b * f);
+        const double c20 = __builtin_fma(b, e, -c * d);
+        const double c11 = __builtin_fma(a, f, -d * d);
+        const double c21 = __builtin_fma(b, d, -a * e);
+        const double c22 = __builtin_fma(a, c, -b * b);
+        const double det = __builtin_fma(a, c00, __builtin_fma(b, c10, d * c20));
+        const double rd = fast_rcp(det);
+        const double i00 = c00 * rd, i10 = c10 * rd, i20 = c20 * rd, i11 = c11 * rd, i21 = c21 * rd, i22 = c22 * rd;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const double x0 = B[0][k], x1 = B[1][k], x2 = B[2][k];
+            B[0][k] = __builtin_fma(i20, x2, __builtin_fma(i10, x1, i00 * x0));
+            B[1][k] = __builtin_fma(i21, x2, __builtin_fma(i11, x1, i10 * x0));
+            B[2][k] = __builtin_fma(i22, x2, __builtin_fma(i21, x1, i20 * x0));
+        }
+        return (a > 0.0) && (c22 > 0.0) && (det > 0.0);
+    }
+};
+template <int NR> struct SmallSpd<4, NR> {
+    __device__ static __forceinline__ bool solve(double (&S)[4][4], double (&B)[4][NR]) {
+        return spd_solve<4, NR, double>(S, B) > 0.0;
+    }
+};
+
+// Hermite -> monomial map of one segment and axis.  xs/xe: free derivatives at the segment's
+// start/end in GLOBAL orientation, dP = P_end - P_start, tp[r] = T^(r+1), ip[e] = T^-e.
+template <int O>
+__device__ __forceinline__ void recover(double Ps, double dP, const double (&xs)[O - 1], const double (&xe)[O - 1],
+                                        const double (&tp)[O - 1], const double (&ip)[2 * O], double (&c)[2 * O]) {
+    constexpr int N = O - 1, M = 2 * O;
+    double hs[N], he[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) { hs[r] = xs[r] * tp[r]; he[r] = xe[r] * tp[r]; }
+#pragma unroll
+    for (int i = 0; i < O; ++i) {
+        // G[i][0] + G[i][O] = 0 for the high rows: positions enter through dP only
+        double acc = Tab<O>::G(i, O) * dP;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            acc = __builtin_fma(Tab<O>::G(i, r + 1), hs[r], acc);
+            acc = __builtin_fma(Tab<O>::G(i, O + r + 1), he[r], acc);
+        }
+        c[i] = acc * ip[M - 1 - i];
+    }
+#pragma unroll
+    for (int j = 1; j < O; ++j) c[M - 1 - j] = xs[j - 1] * Tab<O>::G(M - 1 - j, j);  // derivative j / j!
+    c[M - 1] = Ps;
+}
+
+// LDS geometry of one workgroup (64 trajectories, two waves)
+template <int O, int HS> struct FixedLds {
+    static constexpr int S = 2 * HS;
+    static constexpr int REC = 6 * O;                // doubles per (trajectory, segment) record
+    static constexpr int WP_ROW = (S + 1) * 3;       // doubles per trajectory, unpadded (bank-clean for b64 reads)
+    static constexpr int TM_ROW = S + 2;             // doubles per trajectory, padded against bank conflicts
+    // staging row: the record (+ for order 4 the 8 doubles held over from the pair's other record),
+    // padded so that the row stride in dwords is an odd multiple of 4 (conflict-free ds_write_b128)
+    static constexpr int STAGE_ROW = O == 4 ? 34 : (O == 2 ? 14 : REC);
+    static constexpr int WP_DOUBLES = 64 * WP_ROW;
+    static constexpr int TM_DOUBLES = 64 * TM_ROW;
+    static constexpr int STAGE_DOUBLES = 64 * STAGE_ROW;  // per wave
+    // the Schur carries of the exchange step live at the start of the PARTNER's staging tile
+    // (written before the exchange barrier, read after it, before the tile is used for output)
+    static constexpr int CARRY = (O - 1) * O / 2 + 3 * (O - 1);
+    static_assert(CARRY * 64 <= STAGE_DOUBLES, "carries must fit in a staging tile");
+    static constexpr int TOTAL_DOUBLES = WP_DOUBLES + TM_DOUBLES + 2 * STAGE_DOUBLES;
+    // single-record store burst: LPR lanes per record (16-byte pieces), RPI records per wave store
+    static constexpr int LPR = 3 * O;
+    static constexpr int RPI = 64 / LPR;
+    static constexpr int NI = (64 + RPI - 1) / RPI;
+};
+
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// Input accessor: local (role-oriented) segment times T(j), j = 0..HS-1, and waypoints P(j, axis),
+// j = 0..HS, read on demand from the workgroup's LDS image.  The bottom role walks backwards.
+template <int HS, bool BOTTOM, int TM_STRIDE> struct LdsInputs {
+    const double *l_wp, *l_tm;
+    int lane;
+    __device__ __forceinline__ double T(int j) const { return l_tm[lane * TM_STRIDE + (BOTTOM ? 2 * HS - 1 - j : j)]; }
+    __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * (2 * HS + 1) * 3 + (BOTTOM ? 2 * HS - j : j) * 3 + ax]; }
+};
+
+// STASH: the forward sweep keeps the times/waypoints it reads in registers for the backward sweep,
+// so the LDS input image is dead after the exchange barrier; `after_exchange()` runs right after
+// that barrier (the persistent kernel issues the next slice's LDS-DMA there).
+template <int O, int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
+__device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
+                                           const In &in, double *stage, double *partner_stage,
+                                           const Hook &after_exchange) {
+    constexpr int S = 2 * HS, N = O - 1, M = 2 * O;
+    using L = FixedLds<O, HS>;
+    const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
+    auto Tl = [&](int j) { return in.T(j); };
+    auto Pl = [&](int j, int ax) { return in.P(j, ax); };
+    const double vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
+    // boundary derivatives (minimum_snap.cpp:527-555): vel (order>=2), acc (order>=3) given, every
+    // higher one pinned to 0; time reversal negates odd derivatives
+    auto bc_at = [&](int r, int ax) {
+        return r == 0 ? (BOTTOM ? -bc[1 * 3 + ax] : bc[0 * 3 + ax]) : r == 1 ? (BOTTOM ? bc[3 * 3 + ax] : bc[2 * 3 + ax]) : 0.0;
+    };
+
+    double z[N][3], W[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) z[r][ax] = bc_at(r, ax);
+#pragma unroll
+        for (int c = 0; c < N; ++c) W[r][c] = 0.0;
+    }
+    double Wst[HS][N][N], zst[HS][N][3];  // slot k = local waypoint k (slot 0 unused)
+    bool spd = true;
+
+    // ---- forward elimination over local interior waypoints 1..HS-1 ----
+    Seg<O> left, right;
+    double Tst[HS], Pst[HS + 1][3];  // STASH only
+    { const double t0 = Tl(0); if (STASH) Tst[0] = t0; seg_make<O>(t0, vw, left); }
+    double Pa[3], Pb[3], Pc[3];  // local waypoints k-1, k, k+1
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        Pa[ax] = Pl(0, ax);
+        Pb[ax] = Pl(1, ax);
+        if (STASH) { Pst[0][ax] = Pa[ax]; Pst[1][ax] = Pb[ax]; }
+    }
+#pragma unroll
+    for (int k = 1; k < HS; ++k) {
+        { const double tk = Tl(k); if (STASH) Tst[k] = tk; seg_make<O>(tk, vw, right); }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { Pc[ax] = Pl(k + 1, ax); if (STASH) Pst[k + 1][ax] = Pc[ax]; }
+        double Sm[N][N], R[N][N + 3];  // right-hand sides: [C_k | y_k]
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double v = ee_of<O>(left, r, c) + right.ss[r][c];
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], W[j][c], v);
+                Sm[r][c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c) R[r][c] = right.se[r][c];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+                v = __builtin_fma(right.sp[r], Pc[ax] - Pb[ax], v);
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+                R[r][N + ax] = v;
+            }
+        }
+        spd &= SmallSpd<N, N + 3>::solve(Sm, R);
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) { W[r][c] = R[r][c]; Wst[k][r][c] = R[r][c]; }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { z[r][ax] = R[r][N + ax]; zst[k][r][ax] = R[r][N + ax]; }
+        }
+        left = right;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
+    }
+
+    CSP_STAMP(2);
+    // ---- Schur carry of this half onto the middle waypoint, exchanged through LDS ----
+    double Cm[N][N], cm[N][3];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            double v = ee_of<O>(left, r, c);
+#pragma unroll
+            for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], W[j][c], v);
+            Cm[r][c] = v;
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+            cm[r][ax] = v;
+        }
+    }
+    {
+        double *mine = partner_stage;  // the partner reads it from ITS tile after the barrier
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) mine[(e++) * 64 + lane] = Cm[r][c];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) mine[(e++) * 64 + lane] = cm[r][ax];
+    }
+    lds_barrier();
+    after_exchange();
+    CSP_STAMP(3);
+    double xm[N][3];
+    {
+        const double *other = stage;
+        double Sm[N][N], R[N][3];
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                const double o = other[(e++) * 64 + lane];
+                Sm[r][c] = Cm[r][c] + (((r + c) & 1) ? -o : o);   // the other side's carry, conjugated by the
+            }                                                      // odd-derivative sign flip
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double o = other[(e++) * 64 + lane];
+                R[r][ax] = cm[r][ax] + ((r & 1) ? o : -o);  // derivative r+1 is odd for even r
+            }
+        spd &= SmallSpd<N, 3>::solve(Sm, R);
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xm[r][ax] = R[r][ax];
+    }
+
+    // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
+    double nanacc = 0.0;
+    // bytes between consecutive trajectories' records of one segment: the default layout is
+    // [B][S][3][2o]; CSP_FLAG_SEGMENT_MAJOR selects [S][B][3][2o]
+    constexpr int RECB = L::REC * 8;
+    constexpr int RS = SEGMAJ ? RECB : S * RECB;
+    constexpr int ROW = L::STAGE_ROW;
+    // Output leaves through a lane-major LDS tile and is read back transposed.  For order 4 in the
+    // default layout the records of segments (2q, 2q+1) of one trajectory form one 384-byte,
+    // 128-byte-aligned run, so a wave pairs them: of the first record it stores the 128 bytes that
+    // complete a cache line and holds the other 64 in the tile; with the second record it stores a
+    // 256-byte run.  Every line is then written whole (the single-record scheme left 1/3 of the lines
+    // half-written between two bursts and measured +8 % WRITE_SIZE).  Lane maps of the burst shapes:
+    constexpr bool PAIRING = FULL && !SEGMAJ && O == 4;
+    const int grp = lane / L::LPR;                 // LPR lanes per record (lanes >= RPI*LPR idle)
+    const int lane_in = lane - grp * L::LPR;
+    const int lds_off = grp * ROW + lane_in * 2;   // doubles
+    const unsigned g_off = (unsigned)(grp * RS + lane_in * 16);  // bytes
+    const int l8 = (lane >> 3) * ROW + 8 + (lane & 7) * 2;       // 8 lanes per 128-byte half, tile doubles 8..23
+    const unsigned o8 = (unsigned)((lane >> 3) * RS + (lane & 7) * 16);
+    const int l16 = (lane >> 4) * ROW + (lane & 15) * 2;         // 16 lanes per 256-byte run, tile doubles 0..31
+    const unsigned o16 = (unsigned)((lane >> 4) * RS + (lane & 15) * 16);
+    double xn[N][3];  // free derivatives at local waypoint j+1
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xm[r][ax];
+#pragma unroll
+    for (int j = HS - 1; j >= 0; --j) {
+        double xk[N][3];  // free derivatives at local waypoint j
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (j == 0) {
+                    xk[r][ax] = bc_at(r, ax);
+                } else {
+                    double v = zst[j][r][ax];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) v = __builtin_fma(-Wst[j][r][c], xn[c][ax], v);
+                    xk[r][ax] = v;
+                }
+            }
+        const double Tj = STASH ? Tst[j] : Tl(j);
+        double ip[M], tp[N];
+        ip[0] = 1.0;
+        ip[1] = fast_rcp(Tj);
+#pragma unroll
+        for (int e = 2; e < M; ++e) ip[e] = ip[e - 1] * ip[1];
+        tp[0] = Tj;
+#pragma unroll
+        for (int e = 1; e < N; ++e) tp[e] = tp[e - 1] * Tj;
+        const int g = BOTTOM ? S - 1 - j : j;  // global segment index
+        // the middle pair of an odd half is split between the two waves: those records go out singly
+        const bool paired = PAIRING && !((HS & 1) && g == (BOTTOM ? HS : HS - 1));
+        const bool first = BOTTOM ? (g & 1) == 0 : (g & 1) == 1;  // first record of its pair to reach this wave
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double xs[N], xe[N], c[M];
+            // global orientation: the bottom role's local start is the global END, and odd
+            // derivatives change sign back
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                const double sgn = (BOTTOM && !(r & 1)) ? -1.0 : 1.0;
+                xs[r] = BOTTOM ? sgn * xn[r][ax] : xk[r][ax];
+                xe[r] = BOTTOM ? sgn * xk[r][ax] : xn[r][ax];
+            }
+            const double Plo = STASH ? Pst[j][ax] : Pl(j, ax), Phi = STASH ? Pst[j + 1][ax] : Pl(j + 1, ax);
+            const double Ps = BOTTOM ? Phi : Plo;
+            const double Pe = BOTTOM ? Plo : Phi;
+            recover<O>(Ps, Pe - Ps, xs, xe, tp, ip, c);
+            // lane-major staging tile (row = lane); where the axis block lands depends on the
+            // record's place in its pair (order 4 only, see below)
+            const int tpos = !paired ? ax * M
+                           : (!BOTTOM ? (first ? (ax == 0 ? 24 : ax * M) : ax * M)
+                                      : (first ? (ax == 2 ? 0 : 8 + ax * M) : 8 + ax * M));
+#pragma unroll
+            for (int i = 0; i < M; i += 2) {
+                double2 v2;
+                v2.x = c[i];
+                v2.y = c[i + 1];
+                *reinterpret_cast<double2 *>(stage + lane * ROW + tpos + i) = v2;
+            }
+            if (STATUS) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
+            }
+        }
+        // LDS operations of one wave execute in order, so the tile needs no barrier; the fences only
+        // stop the compiler from reordering the (may-alias) LDS accesses.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (paired) {
+            // pair base = record of the even segment; TOP meets the odd record first, BOTTOM the even one
+            char *pbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + (g & ~1)) * L::REC);  // uniform
+            if (first) {
+                double2 v[8];   // 8 rows x 128 bytes per store
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l8 + i * 8 * ROW);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 0 : 256) + (size_t)i * 8 * RS + o8) = v[i];
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {  // 4 rows x 256 bytes per store, two batches of 8
+                    double2 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l16 + (h * 8 + i) * 4 * ROW);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 128 : 0) + (size_t)(h * 8 + i) * 4 * RS + o16) = v[i];
+                }
+            }
+        } else {
+            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (SEGMAJ ? ((int64_t)g * a.Btotal + a.Boffset + b0) : (b0 * S + g)) * L::REC);  // uniform
+            if (FULL) {
+                // NI stores of RPI whole records each; lanes beyond RPI*LPR and rows beyond 63 are masked
+                // off, not made to repeat a neighbour's piece (duplicates are traffic)
+                if (lane < L::RPI * L::LPR) {
+                    constexpr int NFULL = 64 / L::RPI;      // stores whose RPI rows are all < 64
+                    double2 v[NFULL];
+#pragma unroll
+                    for (int i = 0; i < NFULL; ++i)
+                        v[i] = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
+#pragma unroll
+                    for (int i = 0; i < NFULL; ++i)
+                        *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v[i];
+                    if (NFULL < L::NI && NFULL * L::RPI + grp < 64)   // the ragged last store
+                        *reinterpret_cast<double2 *>(gbase + (size_t)NFULL * L::RPI * RS + g_off) =
+                            *reinterpret_cast<const double2 *>(stage + lds_off + NFULL * L::RPI * ROW);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < L::NI; ++i) {
+                    const int row = i * L::RPI + grp;
+                    if (lane < L::RPI * L::LPR && row < 64 && b0 + row < a.B) {
+                        const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
+                        *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v2;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
+    }
+    CSP_STAMP(4);
+    CSP_STAMP_RT(6);
+    if (STATUS && b0 + lane < a.B) {
+        const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
+        if (bits) atomicOr(a.status + b, bits);
+    }
+}
+
+// FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
+// batch is a second, single-workgroup launch of the FULL=false variant.
+template <int O, int HS, bool STATUS, bool FULL, bool SEGMAJ>
+__global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
+    using L = FixedLds<O, HS>;
+    constexpr int S = 2 * HS;
+    __shared__ __attribute__((aligned(16))) double lds[L::TOTAL_DOUBLES];
+    double *l_wp = lds;
+    double *l_tm = l_wp + L::WP_DOUBLES;
+    double *l_stage = l_tm + L::TM_DOUBLES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int role = tid >> 6;  // wave-uniform
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+
+    CSP_STAMP_RT(5);
+    CSP_STAMP(0);
+    // ---- coalesced copy-in: the workgroup's waypoints and times are contiguous in HBM ----
+    {
+        const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
+        const int n_wp = rows * L::WP_ROW / 2;  // 16-byte pieces
+        constexpr int WP_ITERS = (64 * L::WP_ROW / 2 + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < WP_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            if (c < n_wp) reinterpret_cast<double2 *>(l_wp)[c] = g_wp[c];
+        }
+        if ((rows * L::WP_ROW) & 1) {  // odd number of doubles: last one by itself
+            if (tid == 0) l_wp[rows * L::WP_ROW - 1] = ((const double *)a.wp + b0 * L::WP_ROW)[rows * L::WP_ROW - 1];
+        }
+        const double2 *g_tm = reinterpret_cast<const double2 *>((const double *)a.times + b0 * S);
+        const int n_tm = rows * HS;  // 16-byte pieces
+        constexpr int TM_ITERS = (64 * HS + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < TM_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            const int row = c / HS, col = c - row * HS;
+            if (c < n_tm) *reinterpret_cast<double2 *>(l_tm + row * L::TM_ROW + col * 2) = g_tm[c];
+        }
+    }
+    __syncthreads();
+    CSP_STAMP(1);
+
+    int64_t b = b0 + lane;
+    if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
+    if (role == 0) {
+        const LdsInputs<HS, false, L::TM_ROW> in{l_wp, l_tm, lane};
+        fixed_body<O, HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage, l_stage + L::STAGE_DOUBLES, NoHook{});
+    } else {
+        const LdsInputs<HS, true, L::TM_ROW> in{l_wp, l_tm, lane};
+        fixed_body<O, HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage + L::STAGE_DOUBLES, l_stage, NoHook{});
+    }
+}
+
+// LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no registers in between) of one 64-trajectory
+// slice: waypoints then times, copied linearly in 16-byte pieces, 1 KiB per wave instruction.
+template <int HS> struct SlicePrefetch {
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    typedef __attribute__((address_space(3))) char *lchar_t;
+    static constexpr int S = 2 * HS;
+    static constexpr int WP_ROW = (S + 1) * 3;
+    static constexpr int WP_PIECES = 64 * WP_ROW / 2;   // 64*WP_ROW is even
+    static constexpr int TM_PIECES = 64 * S / 2;
+    static constexpr int WP_ITERS = (WP_PIECES + 127) / 128, TM_ITERS = (TM_PIECES + 127) / 128;
+    static constexpr int TM_BYTE_OFF = 64 * WP_ROW * 8;
+    const char *wp, *tm;     // batch base pointers
+    lchar_t lds3;            // LDS image base (waypoints, then unpadded times)
+    int tid, role;
+    int64_t next, n_slices;
+    __device__ __forceinline__ void issue(int64_t slice) const {
+        const char *g_wp = wp + slice * (64 * WP_ROW * 8);
+        const char *g_tm = tm + slice * (64 * S * 8);
+#pragma unroll
+        for (int it = 0; it < WP_ITERS; ++it) {
+            const int q = it * 128 + tid;  // piece index; a wave's 64 pieces are contiguous
+            if (q < WP_PIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g_wp + (size_t)q * 16), (lptr_t)(lds3 + (it * 128 + role * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < TM_ITERS; ++it) {
+            const int q = it * 128 + tid;
+            if (q < TM_PIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g_tm + (size_t)q * 16), (lptr_t)(lds3 + TM_BYTE_OFF + (it * 128 + role * 64) * 16), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void operator()() const { if (next < n_slices) issue(next); }
+};
+
+template <int O, int HS, bool BOTTOM, bool STATUS, bool SEGMAJ>
+__device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n_slices, int lane, const double *l_wp,
+                                                     const double *l_tm, double *stage, double *partner_stage,
+                                                     SlicePrefetch<HS> pf) {
+    constexpr int S = 2 * HS;
+    using L = FixedLds<O, HS>;
+    // Vector-memory operations a wave issues AFTER a slice's prefetch and before the next top-of-loop
+    // wait: its store bursts.  Must not be over-estimated (the counted wait below relies on at least
+    // this many younger operations existing).  Paired records (order 4, default layout): 8 + 16
+    // stores per pair; single records: NI each.
+    constexpr int PAIRS = (SEGMAJ || O != 4) ? 0 : HS / 2;
+    constexpr int STORES_PER_SLICE = PAIRS * 24 + (HS - 2 * PAIRS) * L::NI;
+    bool first = true;
+    for (int64_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        // the prefetch of this slice is older than every store of the previous slice, so waiting for
+        // all but the youngest min(63, stores) operations covers it without draining the stores
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES_PER_SLICE < 63 ? STORES_PER_SLICE : 63) : "memory");
+        lds_barrier();
+        if (first) CSP_STAMP(1);
+        const LdsInputs<HS, BOTTOM, S> in{l_wp, l_tm, lane};  // unpadded rows: LDS-DMA writes linearly
+        const int64_t b0 = slice * 64;
+        pf.next = slice + gridDim.x;
+        // the image is dead once both waves passed the exchange barrier: prefetch the next slice there
+        fixed_body<O, HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, stage, partner_stage, pf);
+        first = false;
+    }
+}
+
+// Persistent variant for the full workgroups of a batch: gridDim.x workgroups (two per CU) walk the
+// batch with stride gridDim.x; the NEXT slice's inputs stream into LDS while the current slice is
+// back-substituted and stored, so only a workgroup's very first copy-in is exposed.
+template <int O, int HS, bool STATUS, bool SEGMAJ>
+__global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericArgs a, int n_slices) {
+    using L = FixedLds<O, HS>;
+    constexpr int S = 2 * HS;
+    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES];
+    double *l_wp = lds;
+    double *l_tm = l_wp + 64 * L::WP_ROW;
+    double *l_stage = l_tm + 64 * S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int role = tid >> 6;  // wave-uniform
+    SlicePrefetch<HS> pf;
+    pf.wp = reinterpret_cast<const char *>(a.wp);
+    pf.tm = reinterpret_cast<const char *>(a.times);
+    pf.lds3 = (typename SlicePrefetch<HS>::lchar_t)lds;  // cast straight from the LDS object
+    pf.tid = tid;
+    pf.role = role;
+    pf.next = 0;
+    pf.n_slices = n_slices;
+    CSP_STAMP_RT(5);
+    CSP_STAMP(0);
+    if ((int64_t)blockIdx.x < n_slices) pf.issue(blockIdx.x);
+    // one loop per role: each wave's instruction stream holds a single specialisation
+    if (role == 0) persistent_role_loop<O, HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, pf);
+    else persistent_role_loop<O, HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, pf);
+}
+
+// ---- host side: launch one order's kernels -----------------------------------------------------
+// SEGMAJ_OK: whether the segment-major layout is instantiated for this order (order 4 only).
+template <int O, int HS, bool SEGMAJ_OK>
+hipError_t launch_hs(const GenericArgs &a, int cus, hipStream_t st) {
+    const int64_t n_full = a.B / 64, rem = a.B % 64;
+    const dim3 block(128);
+    const int64_t pgrid = n_full < 2 * (int64_t)cus ? n_full : 2 * (int64_t)cus;  // two workgroups per CU
+    GenericArgs t = a;  // tail: the last B % 64 trajectories, one workgroup
+    if (rem) {
+        const int64_t off = n_full * 64;
+        t.B = rem;
+        t.wp = (const double *)a.wp + off * (a.S + 1) * 3;
+        t.times = (const double *)a.times + off * a.S;
+        if (a.seg_major) t.Boffset = off;   // segment-major records are addressed from the batch start
+        else t.coeffs = (double *)a.coeffs + off * a.S * 6 * O;
+        if (a.bc_per_traj) t.bc = (const double *)a.bc + off * 12;
+        if (a.status) t.status = a.status + off;
+        if (a.vw_per) t.vw_per = a.vw_per + off;
+    }
+    auto go = [&](auto status_tag, auto segmaj_tag) {
+        constexpr bool ST = decltype(status_tag)::value, SM = decltype(segmaj_tag)::value;
+        if (n_full) {
+            GenericArgs f = a;
+            f.B = n_full * 64;
+            if (a.persistent) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, HS, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
+            else hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
+        }
+        if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, false, SM>), dim3(1), block, 0, st, t);
+    };
+    if (a.seg_major) {
+        if constexpr (SEGMAJ_OK) {
+            if (a.status) go(std::true_type{}, std::true_type{});
+            else go(std::false_type{}, std::true_type{});
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else {
+        if (a.status) go(std::true_type{}, std::false_type{});
+        else go(std::false_type{}, std::false_type{});
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fixedk
+}  // namespace csp

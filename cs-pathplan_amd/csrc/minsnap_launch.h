@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <cstdio>
 
 namespace csp {
 
@@ -35,11 +36,11 @@ struct GenericArgs {
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
 size_t generic_ws_entries(int order);
 
-// Fixed-size register-resident kernel (minsnap_fixed.hip).  Serves order 4, f64, uniform even
-// S in {2,4,..,16}, penalties off or zero-velocity only.
-bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged);
+// Fixed-size register-resident kernels (minsnap_fixed*.hip): f64, uniform even S, orders 2..5,
+// penalties off or zero-velocity only (bucket table in minsnap_fixed.hip).
+bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged, bool seg_major);
 hipError_t launch_fixed(const GenericArgs &a, hipStream_t st);
-const char *fixed_kernel_name(int S);
+const char *fixed_kernel_name(int order, int S);
 
 struct TimeAllocArgs {
     const void *wp;

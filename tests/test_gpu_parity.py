@@ -121,6 +121,31 @@ def test_persistent_workgroups_walk_several_slices(csp, oracle_mod, S):
     assert synth.rel_err(a[idx], ref) < TOL_WELL
 
 
+@pytest.mark.parametrize("order,S_list", [(2, [2, 6, 16]), (3, [2, 4, 10, 16]), (5, [2, 4, 8])])
+def test_fixed_kernels_of_the_other_orders(csp, oracle_mod, order, S_list):
+    """Orders 2 (the shipped yaml), 3 (the reference's default) and 5 have register-resident buckets
+    too: compare with the generic kernel on a multi-slice batch and with the oracle on samples."""
+    import torch
+    rng = np.random.default_rng(order)
+    for S in S_list:
+        for B in (1, 65, 512 * 64 + 64 * 3 + 7):
+            wp, tm = synth.make_batch(B, S, config_id=60 + order)
+            bc = rng.normal(size=(B, 4, 3))
+            vw = rng.uniform(0.0, 0.3, size=B)
+            d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc, vw)]
+            r = csp.solve_batch(d[0], d[1], d[2], order=order, vel_zero_weight_per_traj=d[3], want_status=True)
+            assert r.kernel == "fixed_o%d_s%d_f64" % (order, S), r.kernel
+            g = csp.solve_batch(d[0], d[1], d[2], order=order, vel_zero_weight_per_traj=d[3], force_generic=True)
+            torch.cuda.synchronize()
+            assert not r.status.cpu().numpy().any()
+            a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
+            assert synth.rel_err(a, gg) < (1e-7 if order == 5 else 1e-9), (order, S, B)
+            for b in sorted({0, B // 2, B - 1}):
+                ref, _ = oracle_mod.solve(order, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], 0.0, float(vw[b]))
+                tol = 1e-6 if order == 5 else TOL_WELL
+                assert synth.rel_err(a[b].reshape(1, -1), ref.reshape(1, -1)) < tol, (order, S, B, b)
+
+
 def test_status_flags_bad_trajectories_only(csp):
     wp, tm = synth.make_batch(130, 16, config_id=3)
     tm[5, 3] = 0.0        # zero-length segment time -> 1/T = inf -> non-finite coefficients
