@@ -205,21 +205,45 @@ template <int HS, bool BOTTOM, int TM_STRIDE> struct LdsInputs {
 // STASH: the forward sweep keeps the times/waypoints it reads in registers for the backward sweep,
 // so the LDS input image is dead after the exchange barrier; `after_exchange()` runs right after
 // that barrier (the persistent kernel issues the next slice's LDS-DMA there).
+// This role's boundary derivatives in its own orientation (minimum_snap.cpp:527-555): velocity
+// (order >= 2) and acceleration (order >= 3) are given, every higher one is pinned to 0; time
+// reversal negates odd derivatives.  Loaded ONCE and kept in registers: re-reading them after the
+// store bursts would force a vmcnt wait that drains every store of the slice.
+template <bool BOTTOM> struct RoleBc {
+    double v[3], acc[3], vw;
+    __device__ __forceinline__ void load(const GenericArgs &a, int64_t b) {
+        const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            v[ax] = BOTTOM ? -bc[1 * 3 + ax] : bc[0 * 3 + ax];
+            acc[ax] = BOTTOM ? bc[3 * 3 + ax] : bc[2 * 3 + ax];
+        }
+        vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
+    }
+    __device__ __forceinline__ double at(int r, int ax) const { return r == 0 ? v[ax] : r == 1 ? acc[ax] : 0.0; }
+    // batch-wide values are wave-uniform: park them in scalar registers for the life of the slice loop
+    __device__ __forceinline__ void to_sgpr() {
+        auto u = [](double x) {
+            const unsigned long long q = __builtin_bit_cast(unsigned long long, x);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+            return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        };
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { v[ax] = u(v[ax]); acc[ax] = u(acc[ax]); }
+        vw = u(vw);
+    }
+};
+
 template <int O, int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
-                                           const In &in, double *stage, double *partner_stage,
-                                           const Hook &after_exchange) {
+                                           const In &in, const RoleBc<BOTTOM> &rbc, double *stage, double *partner_stage,
+                                           double *tst, const Hook &after_exchange) {
     constexpr int S = 2 * HS, N = O - 1, M = 2 * O;
     using L = FixedLds<O, HS>;
-    const double *bc = (const double *)a.bc + (a.bc_per_traj ? b * 12 : 0);
     auto Tl = [&](int j) { return in.T(j); };
     auto Pl = [&](int j, int ax) { return in.P(j, ax); };
-    const double vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
-    // boundary derivatives (minimum_snap.cpp:527-555): vel (order>=2), acc (order>=3) given, every
-    // higher one pinned to 0; time reversal negates odd derivatives
-    auto bc_at = [&](int r, int ax) {
-        return r == 0 ? (BOTTOM ? -bc[1 * 3 + ax] : bc[0 * 3 + ax]) : r == 1 ? (BOTTOM ? bc[3 * 3 + ax] : bc[2 * 3 + ax]) : 0.0;
-    };
+    const double vw = rbc.vw;
+    auto bc_at = [&](int r, int ax) { return rbc.at(r, ax); };
 
     double z[N][3], W[N][N];
 #pragma unroll
@@ -234,8 +258,8 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
     // ---- forward elimination over local interior waypoints 1..HS-1 ----
     Seg<O> left, right;
-    double Tst[HS], Pst[HS + 1][3];  // STASH only
-    { const double t0 = Tl(0); if (STASH) Tst[0] = t0; seg_make<O>(t0, vw, left); }
+    double Pst[HS + 1][3];  // STASH only (the segment times are stashed in LDS: tst[j*64 + lane])
+    { const double t0 = Tl(0); if (STASH) tst[lane] = t0; seg_make<O>(t0, vw, left); }
     double Pa[3], Pb[3], Pc[3];  // local waypoints k-1, k, k+1
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
@@ -245,7 +269,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     }
 #pragma unroll
     for (int k = 1; k < HS; ++k) {
-        { const double tk = Tl(k); if (STASH) Tst[k] = tk; seg_make<O>(tk, vw, right); }
+        { const double tk = Tl(k); if (STASH) tst[k * 64 + lane] = tk; seg_make<O>(tk, vw, right); }
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) { Pc[ax] = Pl(k + 1, ax); if (STASH) Pst[k + 1][ax] = Pc[ax]; }
         double Sm[N][N], R[N][N + 3];  // right-hand sides: [C_k | y_k]
@@ -386,7 +410,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                     xk[r][ax] = v;
                 }
             }
-        const double Tj = STASH ? Tst[j] : Tl(j);
+        const double Tj = STASH ? tst[j * 64 + lane] : Tl(j);
         double ip[M], tp[N];
         ip[0] = 1.0;
         ip[1] = fast_rcp(Tj);
@@ -547,10 +571,14 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
     if (role == 0) {
         const LdsInputs<HS, false, L::TM_ROW> in{l_wp, l_tm, lane};
-        fixed_body<O, HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage, l_stage + L::STAGE_DOUBLES, NoHook{});
+        RoleBc<false> rbc;
+        rbc.load(a, b);
+        fixed_body<O, HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{});
     } else {
         const LdsInputs<HS, true, L::TM_ROW> in{l_wp, l_tm, lane};
-        fixed_body<O, HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, l_stage + L::STAGE_DOUBLES, l_stage, NoHook{});
+        RoleBc<true> rbc;
+        rbc.load(a, b);
+        fixed_body<O, HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{});
     }
 }
 
@@ -570,20 +598,28 @@ template <int HS> struct SlicePrefetch {
     lchar_t lds3;            // LDS image base (waypoints, then unpadded times)
     int tid, role;
     int64_t next, n_slices;
+    // One 16-byte piece per lane, HBM -> LDS at (wave-uniform base + lane*16).  Written as inline asm
+    // on purpose: hipcc's waitcnt insertion answers a pending LDS-DMA with `s_waitcnt vmcnt(0)` in
+    // front of the first LDS read that may alias it, which here would drain the ~100 stores issued
+    // after the prefetch.  The kernel instead waits with a COUNTED vmcnt at the top of the slice loop
+    // (persistent_role_loop) -- this statement is the only place that wait protects.
+    __device__ __forceinline__ void dma16(const char *src, int lds_byte_off) const {
+        const unsigned m0v = (unsigned)(size_t)lds3 + (unsigned)lds_byte_off;  // LDS byte address, wave-uniform
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(m0v)) : "memory", "m0");
+    }
     __device__ __forceinline__ void issue(int64_t slice) const {
         const char *g_wp = wp + slice * (64 * WP_ROW * 8);
         const char *g_tm = tm + slice * (64 * S * 8);
 #pragma unroll
         for (int it = 0; it < WP_ITERS; ++it) {
             const int q = it * 128 + tid;  // piece index; a wave's 64 pieces are contiguous
-            if (q < WP_PIECES)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g_wp + (size_t)q * 16), (lptr_t)(lds3 + (it * 128 + role * 64) * 16), 16, 0, 0);
+            if (q < WP_PIECES) dma16(g_wp + (size_t)q * 16, (it * 128 + role * 64) * 16);
         }
 #pragma unroll
         for (int it = 0; it < TM_ITERS; ++it) {
             const int q = it * 128 + tid;
-            if (q < TM_PIECES)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g_tm + (size_t)q * 16), (lptr_t)(lds3 + TM_BYTE_OFF + (it * 128 + role * 64) * 16), 16, 0, 0);
+            if (q < TM_PIECES) dma16(g_tm + (size_t)q * 16, TM_BYTE_OFF + (it * 128 + role * 64) * 16);
         }
     }
     __device__ __forceinline__ void operator()() const { if (next < n_slices) issue(next); }
@@ -592,7 +628,7 @@ template <int HS> struct SlicePrefetch {
 template <int O, int HS, bool BOTTOM, bool STATUS, bool SEGMAJ>
 __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n_slices, int lane, const double *l_wp,
                                                      const double *l_tm, double *stage, double *partner_stage,
-                                                     SlicePrefetch<HS> pf) {
+                                                     double *tst, SlicePrefetch<HS> pf) {
     constexpr int S = 2 * HS;
     using L = FixedLds<O, HS>;
     // Vector-memory operations a wave issues AFTER a slice's prefetch and before the next top-of-loop
@@ -601,6 +637,12 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
     // stores per pair; single records: NI each.
     constexpr int PAIRS = (SEGMAJ || O != 4) ? 0 : HS / 2;
     constexpr int STORES_PER_SLICE = PAIRS * 24 + (HS - 2 * PAIRS) * L::NI;
+    // Batch-wide boundary conditions / weight are read once, before the loop: a global load inside
+    // the loop could only be waited for together with every older store.  (Per-trajectory boundary
+    // conditions or weights take the one-workgroup-per-slice kernel instead, see launch_hs.)
+    RoleBc<BOTTOM> rbc;
+    rbc.load(a, 0);
+    rbc.to_sgpr();
     bool first = true;
     for (int64_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
         // the prefetch of this slice is older than every store of the previous slice, so waiting for
@@ -613,7 +655,7 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
         const int64_t b0 = slice * 64;
         pf.next = slice + gridDim.x;
         // the image is dead once both waves passed the exchange barrier: prefetch the next slice there
-        fixed_body<O, HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, stage, partner_stage, pf);
+        fixed_body<O, HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, rbc, stage, partner_stage, tst, pf);
         first = false;
     }
 }
@@ -625,10 +667,13 @@ template <int O, int HS, bool STATUS, bool SEGMAJ>
 __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericArgs a, int n_slices) {
     using L = FixedLds<O, HS>;
     constexpr int S = 2 * HS;
-    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES];
+    // image (waypoints, times) | two staging tiles | two time stashes (the forward sweep parks the
+    // segment times it read there: the image is overwritten by the prefetch during the backward sweep)
+    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES + 2 * HS * 64];
     double *l_wp = lds;
     double *l_tm = l_wp + 64 * L::WP_ROW;
     double *l_stage = l_tm + 64 * S;
+    double *l_tst = l_stage + 2 * L::STAGE_DOUBLES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int role = tid >> 6;  // wave-uniform
@@ -644,8 +689,8 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
     CSP_STAMP(0);
     if ((int64_t)blockIdx.x < n_slices) pf.issue(blockIdx.x);
     // one loop per role: each wave's instruction stream holds a single specialisation
-    if (role == 0) persistent_role_loop<O, HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, pf);
-    else persistent_role_loop<O, HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, pf);
+    if (role == 0) persistent_role_loop<O, HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, l_tst, pf);
+    else persistent_role_loop<O, HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, l_tst + HS * 64, pf);
 }
 
 // ---- host side: launch one order's kernels -----------------------------------------------------
@@ -672,7 +717,7 @@ hipError_t launch_hs(const GenericArgs &a, int cus, hipStream_t st) {
         if (n_full) {
             GenericArgs f = a;
             f.B = n_full * 64;
-            if (a.persistent) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, HS, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
+            if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, HS, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
             else hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
         }
         if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, false, SM>), dim3(1), block, 0, st, t);
