@@ -142,16 +142,14 @@ def main():
     wp, tm = synth.make_batch(B, S, config_id=3, offset=rank * B)
     d_wp, d_tm = torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev)
     d_bc = torch.zeros((1, 4, 3), dtype=torch.float64, device=dev)
-    out = torch.empty((B, S, 3, 2 * o), dtype=torch.float64, device=dev)
-    desc = csp.make_desc(o, B, S, csp.DTYPE_F64, mem_space=csp.MEM_DEVICE,
-                         flags=csp.FLAG_FORCE_GENERIC if args.force_generic else 0)
-    ws_bytes = csp.workspace_bytes(desc)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    kernel = csp.kernel_name(desc)
+    # descriptor, buffers and workspace are fixed for the run: a step is exactly one C-ABI call
+    prep = csp.PreparedSolve(d_wp, d_tm, d_bc, order=o, force_generic=args.force_generic,
+                             segment_major=args.segment_major, no_persistent=args.no_persistent,
+                             stream=torch.cuda.current_stream(dev).cuda_stream)
+    out, kernel = prep.out, prep.kernel
 
     def step():
-        csp.solve_batch(d_wp, d_tm, d_bc, order=o, out=out, workspace=ws, force_generic=args.force_generic,
-                        segment_major=args.segment_major, no_persistent=args.no_persistent)
+        prep.run()
 
     def fence():
         if world > 1:

@@ -273,6 +273,45 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     return Result(out, md, stt, kernel_name(desc))
 
 
+class PreparedSolve:
+    """A solve whose descriptor, buffers and workspace are fixed: `run()` is one C-ABI call.
+    For callers that launch the same shape many times (bench.py, a planner's inner loop) --
+    building the descriptor and checking tensors costs more host time than a 40-us kernel."""
+
+    def __init__(self, waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0, out=None,
+                 force_generic=False, segment_major=False, no_persistent=False, stream=None):
+        import torch
+        if not (_is_torch(waypoints) and waypoints.is_cuda):
+            raise ValueError("PreparedSolve takes CUDA tensors (device memory space)")
+        self.dev, tdt = waypoints.device, waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        self.wp, self.tm = waypoints.contiguous(), times.to(tdt).contiguous()
+        B, S = self.tm.shape
+        m = 2 * int(order)
+        self.bc = (torch.zeros((1, 4, 3), dtype=tdt, device=self.dev) if bc is None
+                   else bc.to(tdt).contiguous().reshape(-1, 4, 3))
+        self.out = out if out is not None else torch.empty((S, B, 3, m) if segment_major else (B, S, 3, m), dtype=tdt, device=self.dev)
+        flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
+                 | (FLAG_NO_PERSISTENT if no_persistent else 0))
+        self.desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, self.bc.shape[0] == B and B != 1,
+                              device_id=self.dev.index if self.dev.index is not None else -1, flags=flags)
+        self.ws_bytes = workspace_bytes(self.desc)
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.dev)
+        self.kernel = kernel_name(self.desc)
+        self._stream = stream
+        self._args = (ctypes.byref(self.desc), self.wp.data_ptr(), self.tm.data_ptr(), self.bc.data_ptr(),
+                      self.out.data_ptr(), None, None, self.ws.data_ptr() if self.ws_bytes else None, self.ws_bytes)
+
+    def run(self, stream=None):
+        import torch
+        st = stream if stream is not None else (self._stream if self._stream is not None
+                                                else torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = _lib.csp_minsnap_solve_batch(*self._args, ctypes.c_void_p(st))
+        if rc:
+            _check(rc)
+        return self.out
+
+
 def time_alloc_batch(waypoints, v_avg, min_time_s, seg_offsets=None, stream=None):
     """Batched T_i = max(|dp_i|/V_avg, min_time_s) (math_util/minimum_snap.cpp:63-72)."""
     ragged = seg_offsets is not None
