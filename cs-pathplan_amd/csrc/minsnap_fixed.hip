@@ -2,10 +2,10 @@
 // in minsnap_fixed_impl.h and are instantiated per derivative order in minsnap_fixed_o<O>.hip
 // (separate translation units: they compile in parallel).
 //
-// Buckets served: fp64, uniform even S, no path penalty, and
-//   order 2, 3 : S <= 16        (min-acceleration = the reference's shipped yaml, min-jerk = its default)
-//   order 4    : S <= 16, both coefficient layouts (the headline minimum-snap bucket)
-//   order 5    : S <= 8         (4x4 blocks: 28 doubles per waypoint stay in registers up to 3 waypoints per half)
+// Buckets served: fp64, uniform S (either parity), no path penalty, and
+//   order 2, 3 : 2 <= S <= 16   (min-acceleration = the reference's shipped yaml, min-jerk = its default)
+//   order 4    : 2 <= S <= 16, both coefficient layouts (the headline minimum-snap bucket)
+//   order 5    : 2 <= S <= 8    (4x4 blocks: 28 doubles per waypoint stay in registers up to 3 waypoints per half)
 // Everything else goes to the generic kernel.
 #include "minsnap_launch.h"
 
@@ -13,11 +13,12 @@ namespace csp {
 
 hipError_t launch_fixed_o2(const GenericArgs &a, int cus, hipStream_t st);
 hipError_t launch_fixed_o3(const GenericArgs &a, int cus, hipStream_t st);
-hipError_t launch_fixed_o4(const GenericArgs &a, int cus, hipStream_t st);
+hipError_t launch_fixed_o4a(const GenericArgs &a, int cus, hipStream_t st);   // S = 2..9
+hipError_t launch_fixed_o4b(const GenericArgs &a, int cus, hipStream_t st);   // S = 10..16
 hipError_t launch_fixed_o5(const GenericArgs &a, int cus, hipStream_t st);
 
 bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged, bool seg_major) {
-    if (f32 || ragged || path_weight != 0.0 || S < 2 || (S % 2) != 0) return false;
+    if (f32 || ragged || path_weight != 0.0 || S < 2) return false;
     switch (order) {
         case 2: case 3: return S <= 16 && !seg_major;
         case 4: return S <= 16;
@@ -50,7 +51,7 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
     switch (a.order) {
         case 2: return launch_fixed_o2(a, cus, st);
         case 3: return launch_fixed_o3(a, cus, st);
-        case 4: return launch_fixed_o4(a, cus, st);
+        case 4: return a.S <= 9 ? launch_fixed_o4a(a, cus, st) : launch_fixed_o4b(a, cus, st);
         case 5: return launch_fixed_o5(a, cus, st);
     }
     return hipErrorInvalidValue;

@@ -1,9 +1,10 @@
 // minsnap_fixed_impl.h -- register-resident kernels for the uniform fixed-size buckets
-// (fp64, derivative order O in 2..5, even segment count S = 2*HS, no path penalty).
+// (fp64, derivative order O in 2..5, 2 <= S <= 16 segments of either parity, no path penalty).
 // Instantiated once per order by minsnap_fixed_o<O>.hip; the dispatcher is minsnap_fixed.hip.
 //
 // Mapping: a trajectory is split at its middle waypoint between two WAVES of one
-// workgroup.  Wave 0 ("top") eliminates interior waypoints 1..S/2-1 downwards, wave 1
+// workgroup: the top role owns the first ceil(S/2) segments, the bottom role the other floor(S/2).
+// Wave 0 ("top") eliminates its interior waypoints downwards, wave 1
 // ("bottom") runs the very same code on the time-reversed second half (reversed waypoint order,
 // odd derivatives negated), i.e. a twisted block-LDL^T factorisation of the block-tridiagonal
 // R_PP (minimum_snap.cpp:564-566).  Lane l of both waves owns trajectory 64*slice+l, so every
@@ -169,11 +170,12 @@ __device__ __forceinline__ void recover(double Ps, double dP, const double (&xs)
 }
 
 // LDS geometry of one workgroup (64 trajectories, two waves)
-template <int O, int HS> struct FixedLds {
-    static constexpr int S = 2 * HS;
+template <int O, int S> struct FixedLds {
+    static constexpr int HT = (S + 1) / 2, HB = S / 2;  // segments of the top / bottom role
     static constexpr int REC = 6 * O;                // doubles per (trajectory, segment) record
     static constexpr int WP_ROW = (S + 1) * 3;       // doubles per trajectory, unpadded (bank-clean for b64 reads)
-    static constexpr int TM_ROW = S + 2;             // doubles per trajectory, padded against bank conflicts
+    static constexpr int TM_ROW = S;                 // doubles per trajectory, unpadded (LDS-DMA and the 16-byte
+                                                     // copy-in write linearly; the few time reads tolerate conflicts)
     // staging row: the record (+ for order 4 the 8 doubles held over from the pair's other record),
     // padded so that the row stride in dwords is an odd multiple of 4 (conflict-free ds_write_b128)
     static constexpr int STAGE_ROW = O == 4 ? 34 : (O == 2 ? 14 : REC);
@@ -195,11 +197,11 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // Input accessor: local (role-oriented) segment times T(j), j = 0..HS-1, and waypoints P(j, axis),
 // j = 0..HS, read on demand from the workgroup's LDS image.  The bottom role walks backwards.
-template <int HS, bool BOTTOM, int TM_STRIDE> struct LdsInputs {
+template <int S, bool BOTTOM> struct LdsInputs {
     const double *l_wp, *l_tm;
     int lane;
-    __device__ __forceinline__ double T(int j) const { return l_tm[lane * TM_STRIDE + (BOTTOM ? 2 * HS - 1 - j : j)]; }
-    __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * (2 * HS + 1) * 3 + (BOTTOM ? 2 * HS - j : j) * 3 + ax]; }
+    __device__ __forceinline__ double T(int j) const { return l_tm[lane * S + (BOTTOM ? S - 1 - j : j)]; }
+    __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * (S + 1) * 3 + (BOTTOM ? S - j : j) * 3 + ax]; }
 };
 
 // STASH: the forward sweep keeps the times/waypoints it reads in registers for the backward sweep,
@@ -234,12 +236,13 @@ template <bool BOTTOM> struct RoleBc {
     }
 };
 
-template <int O, int HS, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
+template <int O, int S, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
                                            const In &in, const RoleBc<BOTTOM> &rbc, double *stage, double *partner_stage,
                                            double *tst, const Hook &after_exchange) {
-    constexpr int S = 2 * HS, N = O - 1, M = 2 * O;
-    using L = FixedLds<O, HS>;
+    constexpr int N = O - 1, M = 2 * O;
+    constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;   // segments of THIS role; both roles meet at waypoint ceil(S/2)
+    using L = FixedLds<O, S>;
     auto Tl = [&](int j) { return in.T(j); };
     auto Pl = [&](int j, int ax) { return in.P(j, ax); };
     const double vw = rbc.vw;
@@ -380,7 +383,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     // complete a cache line and holds the other 64 in the tile; with the second record it stores a
     // 256-byte run.  Every line is then written whole (the single-record scheme left 1/3 of the lines
     // half-written between two bursts and measured +8 % WRITE_SIZE).  Lane maps of the burst shapes:
-    constexpr bool PAIRING = FULL && !SEGMAJ && O == 4;
+    constexpr bool PAIRING = FULL && !SEGMAJ && O == 4 && (S % 2) == 0;
     const int grp = lane / L::LPR;                 // LPR lanes per record (lanes >= RPI*LPR idle)
     const int lane_in = lane - grp * L::LPR;
     const int lds_off = grp * ROW + lane_in * 2;   // doubles
@@ -524,10 +527,9 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
 // FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
 // batch is a second, single-workgroup launch of the FULL=false variant.
-template <int O, int HS, bool STATUS, bool FULL, bool SEGMAJ>
+template <int O, int S, bool STATUS, bool FULL, bool SEGMAJ>
 __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
-    using L = FixedLds<O, HS>;
-    constexpr int S = 2 * HS;
+    using L = FixedLds<O, S>;
     __shared__ __attribute__((aligned(16))) double lds[L::TOTAL_DOUBLES];
     double *l_wp = lds;
     double *l_tm = l_wp + L::WP_DOUBLES;
@@ -555,13 +557,15 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
             if (tid == 0) l_wp[rows * L::WP_ROW - 1] = ((const double *)a.wp + b0 * L::WP_ROW)[rows * L::WP_ROW - 1];
         }
         const double2 *g_tm = reinterpret_cast<const double2 *>((const double *)a.times + b0 * S);
-        const int n_tm = rows * HS;  // 16-byte pieces
-        constexpr int TM_ITERS = (64 * HS + 127) / 128;
+        const int n_tm = rows * S / 2;  // 16-byte pieces
+        constexpr int TM_ITERS = (64 * S / 2 + 127) / 128;
 #pragma unroll
         for (int it = 0; it < TM_ITERS; ++it) {
             const int c = it * 128 + tid;
-            const int row = c / HS, col = c - row * HS;
-            if (c < n_tm) *reinterpret_cast<double2 *>(l_tm + row * L::TM_ROW + col * 2) = g_tm[c];
+            if (c < n_tm) reinterpret_cast<double2 *>(l_tm)[c] = g_tm[c];
+        }
+        if ((rows * S) & 1) {
+            if (tid == 0) l_tm[rows * S - 1] = ((const double *)a.times + b0 * S)[rows * S - 1];
         }
     }
     __syncthreads();
@@ -570,25 +574,24 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
     if (role == 0) {
-        const LdsInputs<HS, false, L::TM_ROW> in{l_wp, l_tm, lane};
+        const LdsInputs<S, false> in{l_wp, l_tm, lane};
         RoleBc<false> rbc;
         rbc.load(a, b);
-        fixed_body<O, HS, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{});
+        fixed_body<O, S, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{});
     } else {
-        const LdsInputs<HS, true, L::TM_ROW> in{l_wp, l_tm, lane};
+        const LdsInputs<S, true> in{l_wp, l_tm, lane};
         RoleBc<true> rbc;
         rbc.load(a, b);
-        fixed_body<O, HS, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{});
+        fixed_body<O, S, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{});
     }
 }
 
 // LDS-DMA (global_load_lds_dwordx4: HBM -> LDS, no registers in between) of one 64-trajectory
 // slice: waypoints then times, copied linearly in 16-byte pieces, 1 KiB per wave instruction.
-template <int HS> struct SlicePrefetch {
+template <int S> struct SlicePrefetch {
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     typedef __attribute__((address_space(3))) char *lchar_t;
-    static constexpr int S = 2 * HS;
     static constexpr int WP_ROW = (S + 1) * 3;
     static constexpr int WP_PIECES = 64 * WP_ROW / 2;   // 64*WP_ROW is even
     static constexpr int TM_PIECES = 64 * S / 2;
@@ -606,7 +609,8 @@ template <int HS> struct SlicePrefetch {
     __device__ __forceinline__ void dma16(const char *src, int lds_byte_off) const {
         const unsigned m0v = (unsigned)(size_t)lds3 + (unsigned)lds_byte_off;  // LDS byte address, wave-uniform
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
-                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(m0v)) : "memory", "m0");
+                     :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(m0v)) : "memory");  // m0 is a reserved register: hipcc neither tracks nor relies on it here
+                                      // (gfx950 DS instructions take no m0; this kernel has no other m0 user)
     }
     __device__ __forceinline__ void issue(int64_t slice) const {
         const char *g_wp = wp + slice * (64 * WP_ROW * 8);
@@ -625,17 +629,17 @@ template <int HS> struct SlicePrefetch {
     __device__ __forceinline__ void operator()() const { if (next < n_slices) issue(next); }
 };
 
-template <int O, int HS, bool BOTTOM, bool STATUS, bool SEGMAJ>
+template <int O, int S, bool BOTTOM, bool STATUS, bool SEGMAJ>
 __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n_slices, int lane, const double *l_wp,
                                                      const double *l_tm, double *stage, double *partner_stage,
-                                                     double *tst, SlicePrefetch<HS> pf) {
-    constexpr int S = 2 * HS;
-    using L = FixedLds<O, HS>;
+                                                     double *tst, SlicePrefetch<S> pf) {
+    constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;
+    using L = FixedLds<O, S>;
     // Vector-memory operations a wave issues AFTER a slice's prefetch and before the next top-of-loop
     // wait: its store bursts.  Must not be over-estimated (the counted wait below relies on at least
     // this many younger operations existing).  Paired records (order 4, default layout): 8 + 16
     // stores per pair; single records: NI each.
-    constexpr int PAIRS = (SEGMAJ || O != 4) ? 0 : HS / 2;
+    constexpr int PAIRS = (SEGMAJ || O != 4 || (S % 2) != 0) ? 0 : HS / 2;
     constexpr int STORES_PER_SLICE = PAIRS * 24 + (HS - 2 * PAIRS) * L::NI;
     // Batch-wide boundary conditions / weight are read once, before the loop: a global load inside
     // the loop could only be waited for together with every older store.  (Per-trajectory boundary
@@ -651,11 +655,11 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES_PER_SLICE < 63 ? STORES_PER_SLICE : 63) : "memory");
         lds_barrier();
         if (first) CSP_STAMP(1);
-        const LdsInputs<HS, BOTTOM, S> in{l_wp, l_tm, lane};  // unpadded rows: LDS-DMA writes linearly
+        const LdsInputs<S, BOTTOM> in{l_wp, l_tm, lane};
         const int64_t b0 = slice * 64;
         pf.next = slice + gridDim.x;
         // the image is dead once both waves passed the exchange barrier: prefetch the next slice there
-        fixed_body<O, HS, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, rbc, stage, partner_stage, tst, pf);
+        fixed_body<O, S, BOTTOM, STATUS, true, SEGMAJ, true>(a, b0, b0 + lane, lane, in, rbc, stage, partner_stage, tst, pf);
         first = false;
     }
 }
@@ -663,13 +667,12 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
 // Persistent variant for the full workgroups of a batch: gridDim.x workgroups (two per CU) walk the
 // batch with stride gridDim.x; the NEXT slice's inputs stream into LDS while the current slice is
 // back-substituted and stored, so only a workgroup's very first copy-in is exposed.
-template <int O, int HS, bool STATUS, bool SEGMAJ>
+template <int O, int S, bool STATUS, bool SEGMAJ>
 __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericArgs a, int n_slices) {
-    using L = FixedLds<O, HS>;
-    constexpr int S = 2 * HS;
+    using L = FixedLds<O, S>;
     // image (waypoints, times) | two staging tiles | two time stashes (the forward sweep parks the
     // segment times it read there: the image is overwritten by the prefetch during the backward sweep)
-    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES + 2 * HS * 64];
+    __shared__ __attribute__((aligned(16))) double lds[64 * L::WP_ROW + 64 * S + 2 * L::STAGE_DOUBLES + 2 * L::HT * 64];
     double *l_wp = lds;
     double *l_tm = l_wp + 64 * L::WP_ROW;
     double *l_stage = l_tm + 64 * S;
@@ -677,10 +680,10 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int role = tid >> 6;  // wave-uniform
-    SlicePrefetch<HS> pf;
+    SlicePrefetch<S> pf;
     pf.wp = reinterpret_cast<const char *>(a.wp);
     pf.tm = reinterpret_cast<const char *>(a.times);
-    pf.lds3 = (typename SlicePrefetch<HS>::lchar_t)lds;  // cast straight from the LDS object
+    pf.lds3 = (typename SlicePrefetch<S>::lchar_t)lds;  // cast straight from the LDS object
     pf.tid = tid;
     pf.role = role;
     pf.next = 0;
@@ -689,14 +692,14 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
     CSP_STAMP(0);
     if ((int64_t)blockIdx.x < n_slices) pf.issue(blockIdx.x);
     // one loop per role: each wave's instruction stream holds a single specialisation
-    if (role == 0) persistent_role_loop<O, HS, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, l_tst, pf);
-    else persistent_role_loop<O, HS, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, l_tst + HS * 64, pf);
+    if (role == 0) persistent_role_loop<O, S, false, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage, l_stage + L::STAGE_DOUBLES, l_tst, pf);
+    else persistent_role_loop<O, S, true, STATUS, SEGMAJ>(a, n_slices, lane, l_wp, l_tm, l_stage + L::STAGE_DOUBLES, l_stage, l_tst + L::HT * 64, pf);
 }
 
 // ---- host side: launch one order's kernels -----------------------------------------------------
 // SEGMAJ_OK: whether the segment-major layout is instantiated for this order (order 4 only).
-template <int O, int HS, bool SEGMAJ_OK>
-hipError_t launch_hs(const GenericArgs &a, int cus, hipStream_t st) {
+template <int O, int S, bool SEGMAJ_OK>
+hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
     const int64_t n_full = a.B / 64, rem = a.B % 64;
     const dim3 block(128);
     const int64_t pgrid = n_full < 2 * (int64_t)cus ? n_full : 2 * (int64_t)cus;  // two workgroups per CU
@@ -717,10 +720,10 @@ hipError_t launch_hs(const GenericArgs &a, int cus, hipStream_t st) {
         if (n_full) {
             GenericArgs f = a;
             f.B = n_full * 64;
-            if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, HS, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
-            else hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
+            if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, S, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
+            else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
         }
-        if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, HS, ST, false, SM>), dim3(1), block, 0, st, t);
+        if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, false, SM>), dim3(1), block, 0, st, t);
     };
     if (a.seg_major) {
         if constexpr (SEGMAJ_OK) {

@@ -57,7 +57,9 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(csp.make_desc(2, 100, 6)) == "fixed_o2_s6_f64"
     assert csp.kernel_name(csp.make_desc(5, 100, 8)) == "fixed_o5_s8_f64"
     assert csp.kernel_name(csp.make_desc(5, 100, 10)) == "generic_o5_f64"        # order 5 buckets stop at S = 8
-    assert csp.kernel_name(csp.make_desc(4, 100, 7)) == "generic_o4_f64"         # odd S
+    assert csp.kernel_name(csp.make_desc(4, 100, 7)) == "fixed_o4_s7_f64"        # odd S: 4 + 3 segments
+    assert csp.kernel_name(csp.make_desc(4, 100, 17)) == "generic_o4_f64"
+    assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "generic_o4_f64"
     assert csp.kernel_name(csp.make_desc(3, 100, 16, flags=csp.FLAG_SEGMENT_MAJOR)) == "generic_o3_f64"
     d = csp.make_desc(4, 10, 16, path_weight=1e-3)
     assert csp.kernel_name(d) == "generic_o4_f64"
