@@ -1,0 +1,57 @@
+"""bench.py's own plumbing on the GPU box: the PreparedSolve fast path, the JSON contract, and the
+multi-rank control flow (two ranks rehearsed on ONE GPU over gloo -- CSP_BENCH_SHARE_GPU=1; the real
+N>1 run over RCCL is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_prepared_solve_equals_solve_batch(csp):
+    import torch
+    wp, tm = synth.make_batch(3000, 16, config_id=3)
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    ref = csp.solve_batch(d_wp, d_tm, order=4).coeffs
+    prep = csp.PreparedSolve(d_wp, d_tm, order=4)
+    for _ in range(3):
+        out = prep.run()
+    torch.cuda.synchronize()
+    assert prep.kernel == "fixed_o4_s16_f64"
+    assert torch.equal(out, ref)
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_json_contract_single_gpu():
+    d = _run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--batch", "8192", "--cpu-budget", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity_max_rel_err"] < 1e-6
+
+
+def test_bench_two_ranks_share_one_gpu():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+              "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2",
+              "--batch", "8192"], env={"CSP_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and "cpu_baseline" not in d
