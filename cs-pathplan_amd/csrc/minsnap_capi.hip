@@ -165,7 +165,7 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
     static thread_local char name[64];
     Shape s;
     if (validate(desc, s) != CSP_OK) return nullptr;
-    if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.order, s.S);
+    if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.order, s.S, desc->path_weight > 0.0);
     std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order,
                   !s.f32 ? "f64" : ((desc->flags & CSP_FLAG_F32_ARITH) ? "f32" : "f32io_f64"), s.ragged ? "_ragged" : "");
     return name;
@@ -268,7 +268,6 @@ size_t csp_minsnap_plan_workspace_bytes(const csp_minsnap_desc *desc) {
     Shape s;
     if (validate(desc, s) != CSP_OK) return 0;
     csp_minsnap_desc g = *desc;
-    if (desc->path_weight > 0.0) g.flags |= CSP_FLAG_FORCE_GENERIC;
     Shape gs;
     validate(&g, gs);
     // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32
@@ -346,8 +345,7 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
         return CSP_OK;
     }
 
-    csp_minsnap_desc g = *desc;
-    g.flags |= CSP_FLAG_FORCE_GENERIC;
+    csp_minsnap_desc g = *desc;  // the re-solve loop drives the per-trajectory weight array
     Shape gs;
     validate(&g, gs);
     const size_t need = csp_minsnap_plan_workspace_bytes(desc);

@@ -23,6 +23,7 @@ template <int O> struct Tab;
     template <> struct Tab<o> {                                                             \
         __device__ static constexpr double G(int i, int a) { return tables::G##o[i][a]; }   \
         __device__ static constexpr double QT(int a, int b) { return tables::QT##o[a][b]; } \
+        __device__ static constexpr double HW(int s, int a) { return tables::HW##o[s][a]; } \
     };
 CSP_TAB(1) CSP_TAB(2) CSP_TAB(3) CSP_TAB(4) CSP_TAB(5)
 #undef CSP_TAB

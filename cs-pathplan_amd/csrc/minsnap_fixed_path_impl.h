@@ -1,0 +1,420 @@
+// minsnap_fixed_path_impl.h -- register-resident kernel WITH the path-deviation penalty
+// (reference: math_util/minimum_snap.cpp:347-469 + :511-624), same twisted two-wave mapping as
+// minsnap_fixed_impl.h.  One launch does what the reference does in one SolveQPClosedForm call:
+//
+//   pass A  the unpenalised pre-solve (Q_original: no path term, no zero-velocity term, :349-405),
+//           whose polynomial is sampled at t = T*s/16, s = 0..16, per segment; the first sample of
+//           maximal squared distance to the chord wins (strict '>', :408-439)           -> t*_k
+//   pass B  the penalised solve: per segment a rank-1 term w*h h^T with h = M^-T phi(t*) (the
+//           Hermite weights at t*, from the constant table HW) plus the linear term
+//           f~ = -2 w L(t*) h, applied UN-halved like the reference (:577-579), plus the
+//           zero-velocity term; then recovery, stores and the deviation metric at t* (:594-624).
+//
+// Penalty algebra: for a row of a free derivative x of a segment, with Hermite
+// weight h_x,  the known part of  w*h_x*(h^T d) + f~_x  is  -w*h_x*(P_s + (2*tau - h_endpos)*dP)
+// because h_startpos + h_endpos = 1 and L = P_s + tau*dP; it moves to the right-hand side as
+// +h_x*g with g = w*(P_s + (2*tau - h_endpos)*dP) per axis.  Everything is evaluated in the
+// role's own (possibly time-reversed) frame: the cost terms are frame independent.
+#pragma once
+#include "minsnap_fixed_impl.h"
+
+namespace csp {
+namespace fixedk {
+
+// Per-segment quantities of the penalised system in the role's frame.
+template <int O> struct PSeg {
+    double ip[2 * O];   // T^-e
+    double h[2 * O];    // Hermite weights at t*, including the T^deriv scaling (zero in pass A)
+    double g[3];        // w*(P_s + (2 tau - h_endpos) dP) per axis (zero in pass A)
+    double dP[3];       // P_end - P_start (local frame)
+};
+
+template <int O, bool PEN>
+__device__ __forceinline__ void pseg_make(double T, double pw, int tau_idx, const double *l_hw, const double (&Ps)[3],
+                                          const double (&Pe)[3], PSeg<O> &s) {
+    constexpr int M = 2 * O;
+    s.ip[0] = 1.0;
+    s.ip[1] = fast_rcp(T);
+#pragma unroll
+    for (int e = 2; e < M; ++e) s.ip[e] = s.ip[e - 1] * s.ip[1];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) s.dP[ax] = Pe[ax] - Ps[ax];
+    if (PEN) {
+        double tp[O];
+        tp[0] = 1.0;
+#pragma unroll
+        for (int e = 1; e < O; ++e) tp[e] = tp[e - 1] * T;
+#pragma unroll
+        for (int a = 0; a < M; ++a) s.h[a] = l_hw[tau_idx * M + a] * tp[a % O];
+        const double k = 2.0 * (double)tau_idx * 0.0625 - s.h[O];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) s.g[ax] = pw * __builtin_fma(k, s.dP[ax], Ps[ax]);
+    } else {
+#pragma unroll
+        for (int a = 0; a < M; ++a) s.h[a] = 0.0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) s.g[ax] = 0.0;
+    }
+}
+
+// block entries of Qt(T) + w h h^T (free derivative index r <-> endpoint-derivative index r+1)
+template <int O> __device__ __forceinline__ double q_ss(const PSeg<O> &s, double pw, int r, int c) {
+    return __builtin_fma(pw * s.h[r + 1], s.h[c + 1], Tab<O>::QT(r + 1, c + 1) * s.ip[2 * O - 3 - r - c]);
+}
+template <int O> __device__ __forceinline__ double q_se(const PSeg<O> &s, double pw, int r, int c) {
+    return __builtin_fma(pw * s.h[r + 1], s.h[O + c + 1], Tab<O>::QT(r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c]);
+}
+template <int O> __device__ __forceinline__ double q_ee(const PSeg<O> &s, double pw, int r, int c) {
+    return __builtin_fma(pw * s.h[O + r + 1], s.h[O + c + 1], Tab<O>::QT(O + r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c]);
+}
+
+// One full twisted sweep.  PEN = false: pass A (fills tau[]); PEN = true: pass B (stores, deviation).
+template <int O, int S, bool BOTTOM, bool PEN, bool STATUS, class In>
+__device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int rows, int lane, const In &in,
+                                           const RoleBc<BOTTOM> &rbc, double pw, const double *l_hw, double *stage,
+                                           double *partner_stage, const int *l_skip,
+                                           int (&tau)[BOTTOM ? S / 2 : (S + 1) / 2], bool &spd,
+                                           double &nanacc, double &maxdev) {
+    constexpr int N = O - 1, M = 2 * O;
+    constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;
+    using L = FixedLds<O, S>;
+    const double vw = PEN ? rbc.vw : 0.0;  // the pre-solve uses Q_original (:349)
+    const double w = PEN ? pw : 0.0;
+
+    double z[N][3], W[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) z[r][ax] = rbc.at(r, ax);
+#pragma unroll
+        for (int c = 0; c < N; ++c) W[r][c] = 0.0;
+    }
+    double Wst[HS][N][N], zst[HS][N][3];
+
+    PSeg<O> left, right;
+    double Pa[3], Pb[3], Pc[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { Pa[ax] = in.P(0, ax); Pb[ax] = in.P(1, ax); }
+    pseg_make<O, PEN>(in.T(0), w, tau[0], l_hw, Pa, Pb, left);
+#pragma unroll
+    for (int k = 1; k < HS; ++k) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) Pc[ax] = in.P(k + 1, ax);
+        pseg_make<O, PEN>(in.T(k), w, tau[k], l_hw, Pb, Pc, right);
+        double seL[N][N];  // the left segment's coupling block (used by the matrix AND the right-hand side)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O>(left, w, j, r);
+        double Sm[N][N], R[N][N + 3];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double v = q_ee<O>(left, w, r, c) + q_ss<O>(right, w, r, c);
+                if (r == 0 && c == 0) v += 2.0 * vw;  // both neighbours' velocity terms (:473-509)
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], W[j][c], v);
+                Sm[r][c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c) R[r][c] = q_se<O>(right, w, r, c);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = (Tab<O>::QT(O + r + 1, 0) * left.ip[M - 2 - r]) * left.dP[ax];
+                v = __builtin_fma(Tab<O>::QT(r + 1, 0) * right.ip[M - 2 - r], right.dP[ax], v);
+                if (PEN) {
+                    v = __builtin_fma(left.h[O + r + 1], left.g[ax], v);
+                    v = __builtin_fma(right.h[r + 1], right.g[ax], v);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], z[j][ax], v);
+                R[r][N + ax] = v;
+            }
+        }
+        spd &= SmallSpd<N, N + 3>::solve(Sm, R);
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) { W[r][c] = R[r][c]; Wst[k][r][c] = R[r][c]; }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { z[r][ax] = R[r][N + ax]; zst[k][r][ax] = R[r][N + ax]; }
+        }
+        left = right;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
+    }
+
+    // ---- carry onto the middle waypoint, exchange, middle solve ----
+    double Cm[N][N], cm[N][3];
+    {
+        double seL[N][N];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O>(left, w, j, r);
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double v = q_ee<O>(left, w, r, c);
+                if (r == 0 && c == 0) v += vw;
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], W[j][c], v);
+                Cm[r][c] = v;
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double v = (Tab<O>::QT(O + r + 1, 0) * left.ip[M - 2 - r]) * left.dP[ax];
+                if (PEN) v = __builtin_fma(left.h[O + r + 1], left.g[ax], v);
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], z[j][ax], v);
+                cm[r][ax] = v;
+            }
+        }
+    }
+    lds_barrier();  // the partner is done with whatever it last read from / staged in its tile
+    {
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) partner_stage[(e++) * 64 + lane] = Cm[r][c];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) partner_stage[(e++) * 64 + lane] = cm[r][ax];
+    }
+    lds_barrier();
+    double xn[N][3];
+    {
+        double Sm[N][N], R[N][3];
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                const double o = stage[(e++) * 64 + lane];
+                Sm[r][c] = Cm[r][c] + (((r + c) & 1) ? -o : o);
+            }
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double o = stage[(e++) * 64 + lane];
+                R[r][ax] = cm[r][ax] + ((r & 1) ? o : -o);
+            }
+        spd &= SmallSpd<N, 3>::solve(Sm, R);
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xn[r][ax] = R[r][ax];
+    }
+
+    // ---- backward sweep ----
+    constexpr int RECB = L::REC * 8, RS = S * RECB, ROW = L::STAGE_ROW;
+    const int grp = lane / L::LPR, lane_in = lane - grp * L::LPR;
+    const int lds_off = grp * ROW + lane_in * 2;
+    const unsigned g_off = (unsigned)(grp * RS + lane_in * 16);
+#pragma unroll
+    for (int j = HS - 1; j >= 0; --j) {
+        double xk[N][3];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (j == 0) {
+                    xk[r][ax] = rbc.at(r, ax);
+                } else {
+                    double v = zst[j][r][ax];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) v = __builtin_fma(-Wst[j][r][c], xn[c][ax], v);
+                    xk[r][ax] = v;
+                }
+            }
+        const double Tj = in.T(j);
+        double ip[M], tp[N];
+        ip[0] = 1.0;
+        ip[1] = fast_rcp(Tj);
+#pragma unroll
+        for (int e = 2; e < M; ++e) ip[e] = ip[e - 1] * ip[1];
+        tp[0] = Tj;
+#pragma unroll
+        for (int e = 1; e < N; ++e) tp[e] = tp[e - 1] * Tj;
+        double P0[3], P1[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { P0[ax] = in.P(j, ax); P1[ax] = in.P(j + 1, ax); }
+        if (!PEN) {
+            // pass A: where does the pre-solve polynomial stray farthest from the chord?  Samples in
+            // GLOBAL order 0..16 (the bottom role's frame is reversed), first maximum wins.
+            double dh[3][M];  // scaled endpoint derivatives of the local frame
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                dh[ax][0] = P0[ax];
+                dh[ax][O] = P1[ax];
+#pragma unroll
+                for (int r = 0; r < N; ++r) { dh[ax][r + 1] = xk[r][ax] * tp[r]; dh[ax][O + r + 1] = xn[r][ax] * tp[r]; }
+            }
+            double best = -1.0;
+            int best_s = 0;
+#pragma unroll
+            for (int sg = 0; sg <= 16; ++sg) {
+                const int sl = BOTTOM ? 16 - sg : sg;  // local sample index
+                double d2 = 0.0;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < M; ++q) v = __builtin_fma(Tab<O>::HW(sl, q), dh[ax][q], v);
+                    const double Lc = __builtin_fma((double)sl * 0.0625, P1[ax] - P0[ax], P0[ax]);
+                    d2 = __builtin_fma(v - Lc, v - Lc, d2);
+                }
+                if (d2 > best) { best = d2; best_s = sl; }
+            }
+            tau[j] = best_s;
+        } else {
+            const int g = BOTTOM ? S - 1 - j : j;
+            double d2 = 0.0, len2 = 0.0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double xs[N], xe[N], c[M];
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double sgn = (BOTTOM && !(r & 1)) ? -1.0 : 1.0;
+                    xs[r] = BOTTOM ? sgn * xn[r][ax] : xk[r][ax];
+                    xe[r] = BOTTOM ? sgn * xk[r][ax] : xn[r][ax];
+                }
+                const double Ps = BOTTOM ? P1[ax] : P0[ax], Pe = BOTTOM ? P0[ax] : P1[ax];
+                recover<O>(Ps, Pe - Ps, xs, xe, tp, ip, c);
+#pragma unroll
+                for (int i = 0; i < M; i += 2) {
+                    double2 v2;
+                    v2.x = c[i];
+                    v2.y = c[i + 1];
+                    *reinterpret_cast<double2 *>(stage + lane * ROW + ax * M + i) = v2;
+                }
+                if (STATUS) {
+#pragma unroll
+                    for (int i = 0; i < M; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
+                }
+                // deviation at the recorded t* (:596-617), in the local frame: P(t*) = h^T d
+                double v = __builtin_fma(l_hw[tau[j] * M + O], P1[ax], l_hw[tau[j] * M] * P0[ax]);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    v = __builtin_fma(l_hw[tau[j] * M + r + 1] * tp[r], xk[r][ax], v);
+                    v = __builtin_fma(l_hw[tau[j] * M + O + r + 1] * tp[r], xn[r][ax], v);
+                }
+                const double dp = P1[ax] - P0[ax];
+                const double Lc = __builtin_fma((double)tau[j] * 0.0625, dp, P0[ax]);
+                d2 = __builtin_fma(v - Lc, v - Lc, d2);
+                len2 = __builtin_fma(dp, dp, len2);
+            }
+            {
+                const double seg_len = sqrt(len2);
+                const double ratio = (seg_len > 1e-6) ? sqrt(d2) / seg_len : 0.0;
+                maxdev = ratio > maxdev ? ratio : maxdev;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * L::REC);
+#pragma unroll
+            for (int i = 0; i < L::NI; ++i) {
+                const int row = i * L::RPI + grp;
+                if (lane < L::RPI * L::LPR && row < rows && !l_skip[row]) {
+                    const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
+                    *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v2;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
+    }
+}
+
+template <int O, int S, bool BOTTOM, bool STATUS>
+__device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int rows, int64_t b, int lane,
+                                          const double *l_wp, const double *l_tm, const double *l_hw, double *stage,
+                                          double *partner_stage, const int *l_skip, double *l_dev, int *l_bits) {
+    constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;
+    const LdsInputs<S, BOTTOM> in{l_wp, l_tm, lane};
+    RoleBc<BOTTOM> rbc;
+    rbc.load(a, b);
+    int tau[HS];
+#pragma unroll
+    for (int j = 0; j < HS; ++j) tau[j] = 0;
+    bool spd = true;
+    double nanacc = 0.0, maxdev = 0.0;
+    path_sweep<O, S, BOTTOM, false, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+    spd = true;  // the reported status is the penalised solve's
+    path_sweep<O, S, BOTTOM, true, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+    // the reference's max_deviation is the maximum over ALL segments and the status covers both
+    // halves: the bottom role hands its part to the top role, which writes (plain stores, and only
+    // for live trajectories: a re-solve pass must leave finished trajectories untouched)
+    const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
+    lds_barrier();
+    if (BOTTOM) { l_dev[lane] = maxdev; l_bits[lane] = bits; }
+    lds_barrier();
+    const bool live = lane < rows && !l_skip[lane];
+    if (!BOTTOM && live) {
+        if (a.max_dev) a.max_dev[b] = fmax(maxdev, l_dev[lane]);
+        if (STATUS) a.status[b] = bits | l_bits[lane];
+    }
+}
+
+// One workgroup per 64-trajectory slice (path-penalty solves are not the streaming headline: no
+// persistent/prefetch structure here).  `skip` marks trajectories the re-solve loop has finished.
+template <int O, int S, bool STATUS>
+__global__ void __launch_bounds__(128) minsnap_fixed_path_kernel(GenericArgs a) {
+    using L = FixedLds<O, S>;
+    constexpr int M = 2 * O;
+    __shared__ __attribute__((aligned(16))) double lds[L::WP_DOUBLES + 64 * S + 2 * L::STAGE_DOUBLES + 17 * M + 64 + 64];
+    double *l_wp = lds;
+    double *l_tm = l_wp + L::WP_DOUBLES;
+    double *l_stage = l_tm + 64 * S;
+    double *l_hw = l_stage + 2 * L::STAGE_DOUBLES;
+    double *l_dev = l_hw + 17 * M;
+    int *l_skip = reinterpret_cast<int *>(l_dev + 64);
+    int *l_bits = l_skip + 64;
+    const int tid = threadIdx.x, lane = tid & 63, role = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    {
+        const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
+        const int n_wp = rows * L::WP_ROW / 2;
+        constexpr int WP_ITERS = (64 * L::WP_ROW / 2 + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < WP_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            if (c < n_wp) reinterpret_cast<double2 *>(l_wp)[c] = g_wp[c];
+        }
+        if (((rows * L::WP_ROW) & 1) && tid == 0) l_wp[rows * L::WP_ROW - 1] = ((const double *)a.wp + b0 * L::WP_ROW)[rows * L::WP_ROW - 1];
+        const double2 *g_tm = reinterpret_cast<const double2 *>((const double *)a.times + b0 * S);
+        const int n_tm = rows * S / 2;
+        constexpr int TM_ITERS = (64 * S / 2 + 127) / 128;
+#pragma unroll
+        for (int it = 0; it < TM_ITERS; ++it) {
+            const int c = it * 128 + tid;
+            if (c < n_tm) reinterpret_cast<double2 *>(l_tm)[c] = g_tm[c];
+        }
+        if (((rows * S) & 1) && tid == 0) l_tm[rows * S - 1] = ((const double *)a.times + b0 * S)[rows * S - 1];
+        for (int q = tid; q < 17 * M; q += 128) l_hw[q] = Tab<O>::HW(q / M, q % M);
+        if (tid < 64) l_skip[tid] = (tid < rows && a.skip) ? a.skip[b0 + tid] : 0;
+    }
+    __syncthreads();
+    int64_t b = b0 + lane;
+    if (b >= a.B) b = a.B - 1;
+    if (role == 0) path_role<O, S, false, STATUS>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage, l_stage + L::STAGE_DOUBLES, l_skip, l_dev, l_bits);
+    else path_role<O, S, true, STATUS>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage + L::STAGE_DOUBLES, l_stage, l_skip, l_dev, l_bits);
+}
+
+template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream_t st) {
+    const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
+    if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace fixedk
+}  // namespace csp

@@ -37,10 +37,10 @@ hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStr
 size_t generic_ws_entries(int order);
 
 // Fixed-size register-resident kernels (minsnap_fixed*.hip): f64, uniform 2 <= S <= 16, orders 2..5,
-// penalties off or zero-velocity only (bucket table in minsnap_fixed.hip).
+// zero-velocity penalty everywhere, path penalty for orders 2..4 (bucket table in minsnap_fixed.hip).
 bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged, bool seg_major);
 hipError_t launch_fixed(const GenericArgs &a, hipStream_t st);
-const char *fixed_kernel_name(int order, int S);
+const char *fixed_kernel_name(int order, int S, bool path);
 
 struct TimeAllocArgs {
     const void *wp;

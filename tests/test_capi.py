@@ -62,8 +62,13 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "generic_o4_f64"
     assert csp.kernel_name(csp.make_desc(3, 100, 16, flags=csp.FLAG_SEGMENT_MAJOR)) == "generic_o3_f64"
     d = csp.make_desc(4, 10, 16, path_weight=1e-3)
+    assert csp.kernel_name(d) == "fixedpath_o4_s16_f64"       # pre-solve + t* pick + penalised solve in registers
+    assert csp.workspace_bytes(d) == 0
+    d = csp.make_desc(4, 10, 16, path_weight=1e-3, flags=csp.FLAG_FORCE_GENERIC)
     assert csp.kernel_name(d) == "generic_o4_f64"
     assert csp.workspace_bytes(d) >= 15 * 18 * 10 * 8 + 16 * 10 * 4
+    assert csp.kernel_name(csp.make_desc(5, 10, 8, path_weight=1e-3)) == "generic_o5_f64"
+    assert csp.kernel_name(csp.make_desc(4, 10, 17, path_weight=1e-3)) == "generic_o4_f64"
     d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32)
     assert csp.kernel_name(d) == "generic_o3_f32io_f64"
     d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32, flags=csp.FLAG_F32_ARITH)

@@ -146,6 +146,43 @@ def test_fixed_kernels_of_the_other_orders(csp, oracle_mod, order, S_list):
                 assert synth.rel_err(a[b].reshape(1, -1), ref.reshape(1, -1)) < tol, (order, S, B, b)
 
 
+@pytest.mark.parametrize("order,S_list", [(2, [2, 3, 6, 16]), (3, [2, 5, 12, 16]), (4, [2, 3, 7, 8, 13, 16])])
+def test_path_penalty_register_kernel(csp, oracle_mod, order, S_list):
+    """The path-deviation penalty (pre-solve, 17-sample t* pick, penalised solve, deviation metric;
+    minimum_snap.cpp:347-469, :594-624) in the register-resident kernel: same coefficients, max_dev and
+    status as the generic kernel on whole batches, and as the oracle on sampled trajectories."""
+    import torch
+    rng = np.random.default_rng(100 + order)
+    for S in S_list:
+        for B, pw in ((1, 0.5), (200, 1e-2), (64 * 9 + 13, 2.0)):
+            wp, tm = synth.make_batch(B, S, config_id=80 + order)
+            bc = rng.normal(size=(B, 4, 3))
+            vw = rng.uniform(0.0, 0.3, size=B)
+            d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc, vw)]
+            kw = dict(order=order, path_weight=pw, vel_zero_weight_per_traj=d[3], want_status=True, want_max_dev=True)
+            r = csp.solve_batch(d[0], d[1], d[2], **kw)
+            assert r.kernel == "fixedpath_o%d_s%d_f64" % (order, S), r.kernel
+            g = csp.solve_batch(d[0], d[1], d[2], force_generic=True, **kw)
+            torch.cuda.synchronize()
+            assert not r.status.cpu().numpy().any()
+            a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
+            assert synth.rel_err(a, gg) < 1e-8, (order, S, B)
+            md, mdg = r.max_dev.cpu().numpy(), g.max_dev.cpu().numpy()
+            assert np.max(np.abs(md - mdg)) < 1e-8 * max(1.0, np.max(mdg)), (order, S, B)
+            for b in sorted({0, B // 2, B - 1}):
+                ref, ref_md = oracle_mod.solve(order, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], pw, float(vw[b]))
+                assert synth.rel_err(a[b].reshape(1, -1), ref.reshape(1, -1)) < 1e-7, (order, S, B, b)
+                assert abs(md[b] - ref_md) < 1e-7 * max(1.0, ref_md), (order, S, B, b)
+        # batch-wide boundary conditions and weight, host-memory entry
+        wp, tm = synth.make_batch(70, S, config_id=90 + order)
+        bc1 = rng.normal(size=(1, 4, 3))
+        r = csp.solve_batch(wp, tm, bc1, order=order, path_weight=0.3, vel_zero_weight=0.05, want_max_dev=True)
+        assert r.kernel.startswith("fixedpath_")
+        ref, ref_md = oracle_mod.solve_batch(order, wp, tm, bc1, path_weight=0.3, vel_zero_weight=0.05)
+        assert synth.rel_err(r.coeffs, ref) < 1e-7, (order, S)
+        assert np.max(np.abs(r.max_dev - ref_md)) < 1e-7 * max(1.0, np.max(ref_md))
+
+
 def test_status_flags_bad_trajectories_only(csp):
     wp, tm = synth.make_batch(130, 16, config_id=3)
     tm[5, 3] = 0.0        # zero-length segment time -> 1/T = inf -> non-finite coefficients
