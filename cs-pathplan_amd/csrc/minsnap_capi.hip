@@ -65,8 +65,16 @@ bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
     return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged, (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }
 
+// the multi-lane workspace-free kernel takes what the fixed buckets do not: ragged batches, S > 16,
+// fp32 storage (minsnap_chunked.hip)
+bool use_chunked(const csp_minsnap_desc *d, const Shape &s) {
+    if ((d->flags & CSP_FLAG_FORCE_GENERIC) || use_fixed(d, s)) return false;
+    return csp::chunked_supported(s.order, s.Smax, s.f32 && (d->flags & CSP_FLAG_F32_ARITH), d->path_weight,
+                                  (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
+}
+
 size_t ws_bytes(const csp_minsnap_desc *d, const Shape &s, size_t *tstar_off) {
-    if (use_fixed(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
+    if (use_fixed(d, s) || use_chunked(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
     const size_t ws_elt = (s.f32 && (d->flags & CSP_FLAG_F32_ARITH)) ? 4 : 8;  // workspace holds the arithmetic type
     size_t factors = align_up((size_t)(s.Smax > 1 ? s.Smax - 1 : 0) * csp::generic_ws_entries(s.order) *
                                   (size_t)s.B * ws_elt, 256);
@@ -119,8 +127,10 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.skip = skip;
     // the fixed kernel moves 16-byte pieces (LDS-DMA, ds_read_b128, dwordx4 stores)
     const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
-    if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;
-    hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st) : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
+    if ((use_fixed(d, s) || use_chunked(d, s)) && !aligned) return CSP_ERR_INVALID_ARG;
+    hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st)
+                 : use_chunked(d, s) ? csp::launch_chunked(a, s.f32, s.Smax, st)
+                                     : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;
 }
@@ -166,6 +176,11 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
     Shape s;
     if (validate(desc, s) != CSP_OK) return nullptr;
     if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.order, s.S, desc->path_weight > 0.0);
+    if (use_chunked(desc, s)) {
+        std::snprintf(name, sizeof name, "chunked_o%d_%s_l%d%s", s.order, s.f32 ? "f32io_f64" : "f64",
+                      1 << csp::chunked_lanes_log2(s.Smax), s.ragged ? "_ragged" : "");
+        return name;
+    }
     std::snprintf(name, sizeof name, "generic_o%d_%s%s", s.order,
                   !s.f32 ? "f64" : ((desc->flags & CSP_FLAG_F32_ARITH) ? "f32" : "f32io_f64"), s.ragged ? "_ragged" : "");
     return name;

@@ -1,0 +1,541 @@
+// minsnap_chunked.hip -- workspace-free kernel for ragged and long trajectories (any S <= 256,
+// orders 2..5, fp64 or fp32 storage with fp64 arithmetic, zero-velocity penalty, no path penalty).
+//
+// The generic kernel (minsnap_generic.hip) walks a trajectory with ONE lane and parks the factors
+// W_k, z_k of the block-tridiagonal R_PP (minimum_snap.cpp:564-566) in an HBM workspace -- 2.4x the
+// algorithmic bytes at order 4 -- and a batch of 65536 long trajectories is one wave per SIMD.  Here a
+// trajectory is cut into nch <= LPT chunks of at most 4 segments and LPT lanes of one wave share it
+// (substructuring / nested dissection of the block-tridiagonal system):
+//
+//   1. each lane eliminates the interior waypoints of ITS chunk twice, left-to-right and (on the
+//      time-reversed chunk: reversed waypoints, odd derivatives negated) right-to-left, carrying only
+//      the current factor: that yields the chunk's Schur complement onto its two interface waypoints
+//      (D_L, D_R symmetric, coupling E, right-hand sides r_L, r_R) without storing anything;
+//   2. the interface system -- block-tridiagonal again, nch-1 unknown waypoints -- sits in LDS
+//      (24 doubles per interface at order 4).  Every lane solves it for the two interfaces of its own
+//      chunk by a twisted elimination: Schur carries from the left end up to its left interface and
+//      from the right end down to its right interface, nch-1 block steps for every lane, so the
+//      loop is wave-uniform and needs no storage either;
+//   3. with all derivatives known at both ends the chunk is an independent little trajectory: a
+//      forward sweep keeping W_k, z_k in registers (<= 3 interior waypoints), back-substitution,
+//      Hermite -> monomial recovery (minimum_snap.cpp:582-591) and the stores.
+//
+// HBM traffic is the algorithmic minimum (inputs once -- the re-reads of steps 1/3 hit L1/L2 --,
+// coefficients once); the price is ~3x the arithmetic of the sequential sweep, which one wave per 4..64
+// trajectories instead of one lane per trajectory more than pays for.
+#include "minsnap_fixed_impl.h"
+
+namespace csp {
+namespace chunked {
+
+using fixedk::Seg;
+using fixedk::SmallSpd;
+using fixedk::ee_of;
+using fixedk::seg_make;
+
+constexpr int CMAX = 4;  // segments per chunk
+
+template <typename IO> __device__ __forceinline__ double ld(const IO *p) { return (double)*p; }
+
+// This lane's chunk: c segments starting at segment s0 of a trajectory whose first segment is seg0
+// (global, ragged prefix) and whose first waypoint is point seg0 + b.  REV loads it time-reversed.
+template <typename IO, bool REV>
+__device__ __forceinline__ void load_chunk(const IO *wp, const IO *tm, int64_t pt0, int64_t sg0, int c,
+                                           double (&T)[CMAX], double (&P)[CMAX + 1][3]) {
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) T[i] = (i < c) ? ld(tm + sg0 + (REV ? c - 1 - i : i)) : 1.0;
+#pragma unroll
+    for (int i = 0; i <= CMAX; ++i) {
+        const int64_t q = pt0 + (REV ? c - i : i);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) P[i][ax] = (i <= c) ? ld(wp + q * 3 + ax) : 0.0;
+    }
+}
+
+// Step 1.  Eliminates the chunk's interior waypoints in local order with the START interface x_s as a
+// parameter: x_k = z_k - W_k x_{k+1} - V_k x_s.  Returns the chunk's part of the END interface row
+//   D x_e + X x_s = r        (X only when CROSS; it is E^T for the forward direction).
+template <int O, bool CROSS>
+__device__ __forceinline__ bool chunk_schur(const double (&T)[CMAX], const double (&P)[CMAX + 1][3], int c, double vw,
+                                            double (&D)[O - 1][O - 1], double (&rr)[O - 1][3], double (&X)[O - 1][O - 1]) {
+    constexpr int N = O - 1, NC = N + 3 + (CROSS ? N : 0);
+    double W[N][N], z[N][3], V[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) { W[r][q] = 0.0; V[r][q] = (r == q) ? -1.0 : 0.0; }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) z[r][ax] = 0.0;
+    }
+    Seg<O> left, right;
+    seg_make<O>(T[0], vw, left);
+    double Pa[3], Pb[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { Pa[ax] = P[0][ax]; Pb[ax] = P[1][ax]; }
+    bool spd = true;
+#pragma unroll
+    for (int k = 1; k < CMAX; ++k) {
+        if (k < c) {
+            seg_make<O>(T[k], vw, right);
+            double Sm[N][N], R[N][NC];
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+#pragma unroll
+                for (int q = 0; q <= r; ++q) {
+                    double v = ee_of<O>(left, r, q) + right.ss[r][q];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], W[j][q], v);
+                    Sm[r][q] = v;
+                }
+#pragma unroll
+                for (int q = 0; q < N; ++q) R[r][q] = right.se[r][q];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+                    v = __builtin_fma(right.sp[r], P[k + 1][ax] - Pb[ax], v);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+                    R[r][N + ax] = v;
+                }
+                if (CROSS) {
+#pragma unroll
+                    for (int q = 0; q < N; ++q) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], V[j][q], v);
+                        R[r][N + 3 + q] = v;    // V_k = -S^-1 se^T V_{k-1}
+                    }
+                }
+            }
+            spd &= SmallSpd<N, NC>::solve(Sm, R);
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) { W[r][q] = R[r][q]; if (CROSS) V[r][q] = R[r][N + 3 + q]; }
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) z[r][ax] = R[r][N + ax];
+            }
+            left = right;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = P[k + 1][ax]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            double v = ee_of<O>(left, r, q), x = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                v = __builtin_fma(-left.se[j][r], W[j][q], v);
+                if (CROSS) x = __builtin_fma(-left.se[j][r], V[j][q], x);
+            }
+            D[r][q] = v;
+            if (CROSS) X[r][q] = x;
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double v = left.ep[r] * (Pb[ax] - Pa[ax]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
+            rr[r][ax] = v;
+        }
+    }
+    return spd;
+}
+
+template <typename IO, int M> __device__ __forceinline__ void store_axis(IO *dst, const double (&c)[M]);
+template <> __device__ __forceinline__ void store_axis<double, 4>(double *d, const double (&c)[4]) {
+    reinterpret_cast<double2 *>(d)[0] = make_double2(c[0], c[1]);
+    reinterpret_cast<double2 *>(d)[1] = make_double2(c[2], c[3]);
+}
+template <> __device__ __forceinline__ void store_axis<double, 6>(double *d, const double (&c)[6]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) reinterpret_cast<double2 *>(d)[i] = make_double2(c[2 * i], c[2 * i + 1]);
+}
+template <> __device__ __forceinline__ void store_axis<double, 8>(double *d, const double (&c)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<double2 *>(d)[i] = make_double2(c[2 * i], c[2 * i + 1]);
+}
+template <> __device__ __forceinline__ void store_axis<double, 10>(double *d, const double (&c)[10]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) reinterpret_cast<double2 *>(d)[i] = make_double2(c[2 * i], c[2 * i + 1]);
+}
+template <> __device__ __forceinline__ void store_axis<float, 4>(float *d, const double (&c)[4]) {
+    reinterpret_cast<float4 *>(d)[0] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+}
+template <> __device__ __forceinline__ void store_axis<float, 6>(float *d, const double (&c)[6]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) reinterpret_cast<float2 *>(d)[i] = make_float2((float)c[2 * i], (float)c[2 * i + 1]);
+}
+template <> __device__ __forceinline__ void store_axis<float, 8>(float *d, const double (&c)[8]) {
+    reinterpret_cast<float4 *>(d)[0] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+    reinterpret_cast<float4 *>(d)[1] = make_float4((float)c[4], (float)c[5], (float)c[6], (float)c[7]);
+}
+template <> __device__ __forceinline__ void store_axis<float, 10>(float *d, const double (&c)[10]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) reinterpret_cast<float2 *>(d)[i] = make_float2((float)c[2 * i], (float)c[2 * i + 1]);
+}
+
+// LDS image of the interface system, one slot per lane: [entry][64] doubles.
+template <int O> struct IfaceLds {
+    static constexpr int N = O - 1;
+    static constexpr int ND = N * (N + 1) / 2;   // D lower triangle
+    static constexpr int OFF_R = ND, OFF_E = ND + 3 * N, ENTRIES = ND + 3 * N + N * N;
+};
+
+template <int O, typename IO>
+__global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
+    constexpr int N = O - 1, M = 2 * O;
+    using IL = IfaceLds<O>;
+    __shared__ double lds[IL::ENTRIES * 64];
+    const int lane = threadIdx.x;
+    const int lpt = 1 << lpt_log2;
+    const int j = lane & (lpt - 1);                                  // my chunk
+    const int64_t b = ((int64_t)blockIdx.x * 64 + lane) >> lpt_log2;  // my trajectory
+    const bool traj_ok = b < a.B;
+    const int64_t bb = traj_ok ? b : a.B - 1;
+    int64_t seg0;
+    int S;
+    if (a.seg_off) { seg0 = a.seg_off[bb]; S = (int)(a.seg_off[bb + 1] - seg0); }
+    else { seg0 = bb * (int64_t)a.S; S = a.S; }
+    if (!traj_ok) S = 0;
+    const int nch = S < lpt ? S : lpt;          // chunks in use (S >= 1 for a real trajectory)
+    const int q = nch > 0 ? S / nch : 0, rem = nch > 0 ? S - q * nch : 0;
+    const bool active = j < nch;
+    const int c = active ? q + (j < rem ? 1 : 0) : 0;            // my segments: s0 .. s0+c-1
+    const int s0 = j * q + (j < rem ? j : rem);
+    const IO *wp = (const IO *)a.wp, *tm = (const IO *)a.times;
+    const int64_t pt0 = seg0 + bb + s0, sg0 = seg0 + s0;
+    const double vw = a.vw_per ? a.vw_per[bb] : a.vel_zero_weight;
+
+    // trajectory boundary derivatives (minimum_snap.cpp:527-555): v, a given, higher ones pinned to 0
+    double x0[N][3], xn[N][3];
+    {
+        const IO *bc = (const IO *)a.bc + (a.bc_per_traj ? bb * 12 : 0);
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                x0[r][ax] = r == 0 ? ld(bc + 0 * 3 + ax) : r == 1 ? ld(bc + 2 * 3 + ax) : 0.0;
+                xn[r][ax] = r == 0 ? ld(bc + 1 * 3 + ax) : r == 1 ? ld(bc + 3 * 3 + ax) : 0.0;
+            }
+    }
+
+    bool spd = true;
+    double T[CMAX], P[CMAX + 1][3];
+    // ---- step 1: the chunk's Schur complement onto its two interfaces ----
+    double DR[N][N], rR[N][3];
+    {
+        double DL[N][N], rL[N][3], Et[N][N], unused[N][N];
+        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
+        spd &= chunk_schur<O, true>(T, P, c, vw, DR, rR, Et);            // end row: DR x_R + Et x_L = rR
+        load_chunk<IO, true>(wp, tm, pt0, sg0, c, T, P);
+        spd &= chunk_schur<O, false>(T, P, c, vw, DL, rL, unused);       // reversed frame: start row
+        if (active) {
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int qq = 0; qq <= r; ++qq) lds[(e++) * 64 + lane] = ((r + qq) & 1) ? -DL[r][qq] : DL[r][qq];
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) lds[(e++) * 64 + lane] = (r & 1) ? rL[r][ax] : -rL[r][ax];  // derivative r+1 is odd for even r
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int qq = 0; qq < N; ++qq) lds[(e++) * 64 + lane] = Et[qq][r];                        // E = Et^T
+        }
+    }
+    __syncthreads();
+    // interface i (1 <= i <= nch-1) sums chunk i-1's end row and chunk i's start row: lane i-1 adds its part
+    if (active && j + 1 < nch) {
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int qq = 0; qq <= r; ++qq) { lds[e * 64 + lane + 1] += DR[r][qq]; ++e; }
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { lds[e * 64 + lane + 1] += rR[r][ax]; ++e; }
+    }
+    __syncthreads();
+
+    // ---- step 2: twisted elimination of the interface system; this lane wants x_jj and x_jj+1 ----
+    double xL[N][3], xR[N][3];
+    {
+        const int base = lane - j;
+        const int jj = (j < nch - 2) ? j : (nch - 2 > 0 ? nch - 2 : 0);
+        double cS[N][N], cr[N][3];     // current Schur carry onto the next interface
+        double lS[N][N], lr[N][3];     // the finished left carry (onto interface jj+1)
+        double Wf[N][N], zc[N][3], WL[N][N], zL[N][3], rinit[N][3];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int qq = 0; qq < N; ++qq) { cS[r][qq] = 0.0; lS[r][qq] = 0.0; Wf[r][qq] = 0.0; WL[r][qq] = 0.0; }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { cr[r][ax] = 0.0; lr[r][ax] = 0.0; zc[r][ax] = 0.0; zL[r][ax] = 0.0; rinit[r][ax] = 0.0; }
+        }
+        if (active) {
+            // the known ends enter as right-hand sides: -E_0^T x_0 onto interface 1, -E_{nch-1} x_n onto nch-1
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int qq = 0; qq < N; ++qq) {
+                    const double e0 = lds[(IL::OFF_E + qq * N + r) * 64 + base];               // E_0[qq][r]
+                    const double en = lds[(IL::OFF_E + r * N + qq) * 64 + base + nch - 1];     // E_{nch-1}[r][qq]
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        cr[r][ax] = __builtin_fma(-e0, x0[qq][ax], cr[r][ax]);
+                        rinit[r][ax] = __builtin_fma(-en, xn[qq][ax], rinit[r][ax]);
+                    }
+                }
+        }
+        for (int t = 0; __builtin_amdgcn_ballot_w64(t <= nch - 2) != 0; ++t) {
+            if (t == jj) {   // the left sweep has reached my left interface: keep its result, start from the right end
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+#pragma unroll
+                    for (int qq = 0; qq < N; ++qq) { lS[r][qq] = cS[r][qq]; WL[r][qq] = Wf[r][qq]; cS[r][qq] = 0.0; }
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) { lr[r][ax] = cr[r][ax]; zL[r][ax] = zc[r][ax]; cr[r][ax] = rinit[r][ax]; }
+                }
+            }
+            if (t < nch - 2) {
+                const bool isleft = t < jj;
+                const int i = isleft ? t + 1 : nch - 1 - (t - jj);
+                const int slotD = base + i, slotE = base + (isleft ? i : i - 1);
+                const int sr = isleft ? N : 1, sc = isleft ? 1 : N;   // F = E_i (left) or E_{i-1}^T (right)
+                double Sm[N][N], R[N][N + 3], F[N][N];
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int qq = 0; qq <= r; ++qq) Sm[r][qq] = lds[(e++) * 64 + slotD] + cS[r][qq];
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) R[r][N + ax] = lds[(e++) * 64 + slotD] + cr[r][ax];
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int qq = 0; qq < N; ++qq) { F[r][qq] = lds[(IL::OFF_E + r * sr + qq * sc) * 64 + slotE]; R[r][qq] = F[r][qq]; }
+                spd &= SmallSpd<N, N + 3>::solve(Sm, R);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+#pragma unroll
+                    for (int qq = 0; qq < N; ++qq) Wf[r][qq] = R[r][qq];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) zc[r][ax] = R[r][N + ax];
+                }
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+#pragma unroll
+                    for (int qq = 0; qq <= r; ++qq) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], Wf[k][qq], v);
+                        cS[r][qq] = v;
+                    }
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], zc[k][ax], v);
+                        cr[r][ax] = v;
+                    }
+                }
+            }
+        }
+        // both carries now sit on interface jj+1; x_jj follows from the last left step
+        double xa[N][3], xb[N][3];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { xa[r][ax] = x0[r][ax]; xb[r][ax] = xn[r][ax]; }
+        if (active && nch >= 2) {
+            const int slotD = base + jj + 1;
+            double Sm[N][N], R[N][3];
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int qq = 0; qq <= r; ++qq) Sm[r][qq] = lds[(e++) * 64 + slotD] + lS[r][qq] + cS[r][qq];
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) R[r][ax] = lds[(e++) * 64 + slotD] + lr[r][ax] + cr[r][ax];
+            spd &= SmallSpd<N, 3>::solve(Sm, R);
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    xb[r][ax] = R[r][ax];
+                }
+            if (jj >= 1) {
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        double v = zL[r][ax];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-WL[r][k], R[k][ax], v);
+                        xa[r][ax] = v;
+                    }
+            }
+        }
+        const bool last = (nch >= 2) && (j == nch - 1);   // the last chunk rode along with its left neighbour
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                xL[r][ax] = last ? xb[r][ax] : xa[r][ax];
+                xR[r][ax] = last ? xn[r][ax] : xb[r][ax];
+            }
+    }
+
+    // ---- step 3: the chunk as a little trajectory with every derivative known at both ends ----
+    double nanacc = 0.0;
+    if (active) {
+        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
+        double W[N][N], z[N][3];
+        double Wst[CMAX][N][N], zst[CMAX][N][3];   // slot k = local waypoint k (slot 0 unused)
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int qq = 0; qq < N; ++qq) W[r][qq] = 0.0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) z[r][ax] = xL[r][ax];
+        }
+        Seg<O> left, right;
+        seg_make<O>(T[0], vw, left);
+#pragma unroll
+        for (int k = 1; k < CMAX; ++k) {
+            if (k < c) {
+                seg_make<O>(T[k], vw, right);
+                double Sm[N][N], R[N][N + 3];
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+#pragma unroll
+                    for (int qq = 0; qq <= r; ++qq) {
+                        double v = ee_of<O>(left, r, qq) + right.ss[r][qq];
+#pragma unroll
+                        for (int jx = 0; jx < N; ++jx) v = __builtin_fma(-left.se[jx][r], W[jx][qq], v);
+                        Sm[r][qq] = v;
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < N; ++qq) R[r][qq] = right.se[r][qq];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        double v = left.ep[r] * (P[k][ax] - P[k - 1][ax]);
+                        v = __builtin_fma(right.sp[r], P[k + 1][ax] - P[k][ax], v);
+#pragma unroll
+                        for (int jx = 0; jx < N; ++jx) v = __builtin_fma(-left.se[jx][r], z[jx][ax], v);
+                        R[r][N + ax] = v;
+                    }
+                }
+                spd &= SmallSpd<N, N + 3>::solve(Sm, R);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+#pragma unroll
+                    for (int qq = 0; qq < N; ++qq) { W[r][qq] = R[r][qq]; Wst[k][r][qq] = R[r][qq]; }
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) { z[r][ax] = R[r][N + ax]; zst[k][r][ax] = R[r][N + ax]; }
+                }
+                left = right;
+            }
+        }
+        double xnx[N][3];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xnx[r][ax] = xR[r][ax];
+        IO *co = (IO *)a.coeffs + (sg0) * (int64_t)(3 * M);
+#pragma unroll
+        for (int s = CMAX - 1; s >= 0; --s) {
+            if (s < c) {
+                double xk[N][3];
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (s == 0) {
+                            xk[r][ax] = xL[r][ax];
+                        } else {
+                            double v = zst[s][r][ax];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) v = __builtin_fma(-Wst[s][r][k], xnx[k][ax], v);
+                            xk[r][ax] = v;
+                        }
+                    }
+                const double Ts = T[s];
+                double ip[M], tp[N];
+                ip[0] = 1.0;
+                ip[1] = fast_rcp(Ts);
+#pragma unroll
+                for (int e = 2; e < M; ++e) ip[e] = ip[e - 1] * ip[1];
+                tp[0] = Ts;
+#pragma unroll
+                for (int e = 1; e < N; ++e) tp[e] = tp[e - 1] * Ts;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    double xs[N], xe[N], cc[M];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { xs[r] = xk[r][ax]; xe[r] = xnx[r][ax]; }
+                    fixedk::recover<O>(P[s][ax], P[s + 1][ax] - P[s][ax], xs, xe, tp, ip, cc);
+                    store_axis<IO, M>(co + (int64_t)s * (3 * M) + ax * M, cc);
+#pragma unroll
+                    for (int i = 0; i < M; ++i) nanacc = __builtin_fma((double)(IO)cc[i], 0.0, nanacc);
+                }
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) xnx[r][ax] = xk[r][ax];
+            }
+        }
+    }
+    if (a.status && active) {
+        const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
+        if (bits) atomicOr(a.status + b, bits);
+    }
+}
+
+template <int O> hipError_t launch_o(const GenericArgs &a, bool f32, int lpt_log2, hipStream_t st) {
+    const int64_t lanes = a.B << lpt_log2;
+    const dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
+    if (f32) hipLaunchKernelGGL((minsnap_chunked_kernel<O, float>), grid, block, 0, st, a, lpt_log2);
+    else hipLaunchKernelGGL((minsnap_chunked_kernel<O, double>), grid, block, 0, st, a, lpt_log2);
+    return hipGetLastError();
+}
+
+}  // namespace chunked
+
+int chunked_lanes_log2(int Smax) {
+    int l = 0;
+    while ((chunked::CMAX << l) < Smax) ++l;
+    return l;
+}
+
+bool chunked_supported(int order, int Smax, bool f32_arith, double path_weight, bool seg_major) {
+    return order >= 2 && order <= 5 && Smax >= 1 && Smax <= chunked::CMAX * 64 && !f32_arith && path_weight == 0.0 && !seg_major;
+}
+
+hipError_t launch_chunked(const GenericArgs &a, bool f32, int Smax, hipStream_t st) {
+    if (a.B == 0) return hipSuccess;
+    hipError_t e;
+    if (a.status && (e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.B, st)) != hipSuccess) return e;
+    // no path penalty: the deviation metric is evaluated at t* = 0 where it vanishes (minimum_snap.cpp:342)
+    if (a.max_dev && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
+    const int l = chunked_lanes_log2(Smax);
+    switch (a.order) {
+        case 2: return chunked::launch_o<2>(a, f32, l, st);
+        case 3: return chunked::launch_o<3>(a, f32, l, st);
+        case 4: return chunked::launch_o<4>(a, f32, l, st);
+        case 5: return chunked::launch_o<5>(a, f32, l, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace csp

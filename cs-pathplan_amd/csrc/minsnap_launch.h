@@ -42,6 +42,12 @@ bool fixed_supported(int order, int S, bool f32, double path_weight, bool ragged
 hipError_t launch_fixed(const GenericArgs &a, hipStream_t st);
 const char *fixed_kernel_name(int order, int S, bool path);
 
+// Workspace-free multi-lane kernel for ragged / long trajectories (minsnap_chunked.hip): orders 2..5,
+// S <= 256, f64 or f32 storage (fp64 arithmetic), zero-velocity penalty, no path penalty.
+bool chunked_supported(int order, int Smax, bool f32_arith, double path_weight, bool seg_major);
+int chunked_lanes_log2(int Smax);
+hipError_t launch_chunked(const GenericArgs &a, bool f32, int Smax, hipStream_t st);
+
 struct TimeAllocArgs {
     const void *wp;
     void *times;

@@ -56,10 +56,16 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(csp.make_desc(3, 100, 16)) == "fixed_o3_s16_f64"
     assert csp.kernel_name(csp.make_desc(2, 100, 6)) == "fixed_o2_s6_f64"
     assert csp.kernel_name(csp.make_desc(5, 100, 8)) == "fixed_o5_s8_f64"
-    assert csp.kernel_name(csp.make_desc(5, 100, 10)) == "generic_o5_f64"        # order 5 buckets stop at S = 8
+    assert csp.kernel_name(csp.make_desc(5, 100, 10)) == "chunked_o5_f64_l4"     # order 5 buckets stop at S = 8
+    assert csp.kernel_name(csp.make_desc(5, 100, 10, flags=csp.FLAG_FORCE_GENERIC)) == "generic_o5_f64"
     assert csp.kernel_name(csp.make_desc(4, 100, 7)) == "fixed_o4_s7_f64"        # odd S: 4 + 3 segments
-    assert csp.kernel_name(csp.make_desc(4, 100, 17)) == "generic_o4_f64"
-    assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "generic_o4_f64"
+    assert csp.kernel_name(csp.make_desc(4, 100, 17)) == "chunked_o4_f64_l8"     # long: 8 lanes x <= 4 segments
+    assert csp.kernel_name(csp.make_desc(4, 100, 64)) == "chunked_o4_f64_l16"
+    assert csp.kernel_name(csp.make_desc(4, 100, 256)) == "chunked_o4_f64_l64"
+    assert csp.workspace_bytes(csp.make_desc(4, 100, 256)) == 0
+    assert csp.kernel_name(csp.make_desc(4, 100, 257)) == "generic_o4_f64"
+    assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "chunked_o4_f64_l1"
+    assert csp.kernel_name(csp.make_desc(1, 100, 5)) == "generic_o1_f64"         # order 1 has no free derivative
     assert csp.kernel_name(csp.make_desc(3, 100, 16, flags=csp.FLAG_SEGMENT_MAJOR)) == "generic_o3_f64"
     d = csp.make_desc(4, 10, 16, path_weight=1e-3)
     assert csp.kernel_name(d) == "fixedpath_o4_s16_f64"       # pre-solve + t* pick + penalised solve in registers
@@ -70,6 +76,8 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(csp.make_desc(5, 10, 8, path_weight=1e-3)) == "generic_o5_f64"
     assert csp.kernel_name(csp.make_desc(4, 10, 17, path_weight=1e-3)) == "generic_o4_f64"
     d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32)
+    assert csp.kernel_name(d) == "chunked_o3_f32io_f64_l2"
+    d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32, flags=csp.FLAG_FORCE_GENERIC)
     assert csp.kernel_name(d) == "generic_o3_f32io_f64"
     d = csp.make_desc(3, 10, 7, dtype=csp.DTYPE_F32, flags=csp.FLAG_F32_ARITH)
     assert csp.kernel_name(d) == "generic_o3_f32"

@@ -248,7 +248,7 @@ def test_f32_storage_mixed_batch_c5(csp, oracle_mod):
     spec.loader.exec_module(mixed)
     trajs = synth.make_ragged(240)
     got, kernels = mixed.solve_mixed(trajs, dtype=np.float32)
-    assert all(k.startswith("generic_o") and k.endswith("f32io_f64_ragged") for k in kernels), kernels
+    assert all(k.startswith("chunked_o") and "f32io_f64" in k and k.endswith("_ragged") for k in kernels), kernels
     got32, _ = mixed.solve_mixed(trajs, dtype=np.float32, f32_arith=True)
     worst = {3: 0.0, 4: 0.0, 5: 0.0}
     worst32 = {3: 0.0, 4: 0.0, 5: 0.0}
@@ -276,6 +276,72 @@ def test_ragged_batch(csp, oracle_mod):
         ref, _ = oracle_mod.solve(4, w, np.zeros((2, 3)), np.zeros((2, 3)), t)
         got = r.coeffs[off[i]:off[i + 1]]
         assert synth.rel_err(got.reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, i
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order):
+    """The workspace-free multi-lane kernel (ragged batches, S > 16, fp32 storage): whole batches against
+    the generic kernel, sampled trajectories against the oracle.  Covers every lanes-per-trajectory
+    bucket (S <= 4 .. S <= 256), chunk sizes 1..4, per-trajectory boundary conditions and weights."""
+    import torch
+    rng = np.random.default_rng(200 + order)
+    tol_g = 1e-6 if order == 5 else 1e-8
+    for smin, smax, B in ((1, 4, 300), (1, 9, 257), (3, 16, 200), (5, 33, 150), (17, 64, 130), (60, 130, 40), (200, 256, 9)):
+        S_b = rng.integers(smin, smax + 1, size=B)
+        S_b[0], S_b[-1] = smin, smax
+        off = np.concatenate([[0], np.cumsum(S_b)]).astype(np.int64)
+        wps, tms = [], []
+        for i, S in enumerate(S_b):
+            p0 = rng.uniform(-10.0, 10.0, size=(1, 3))
+            wps.append(np.concatenate([p0, p0 + np.cumsum(rng.normal(size=(int(S), 3)), axis=0)]))
+            tms.append(rng.uniform(0.5, 2.0, size=int(S)))
+        wp, tm = np.concatenate(wps), np.concatenate(tms)
+        bc = rng.normal(size=(B, 4, 3))
+        vw = rng.uniform(0.0, 0.3, size=B)
+        d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc, vw)]
+        d_off = torch.from_numpy(off).cuda()
+        kw = dict(order=order, seg_offsets=d_off, max_segments=int(smax), vel_zero_weight_per_traj=d[3], want_status=True, want_max_dev=True)
+        r = csp.solve_batch(d[0], d[1], d[2], **kw)
+        assert r.kernel.startswith("chunked_o%d_f64_l" % order) and r.kernel.endswith("_ragged"), r.kernel
+        g = csp.solve_batch(d[0], d[1], d[2], force_generic=True, **kw)
+        torch.cuda.synchronize()
+        assert not r.status.cpu().numpy().any(), (order, smax)
+        assert not r.max_dev.cpu().numpy().any()
+        a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
+        for i in range(B):
+            e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), gg[off[i]:off[i + 1]].reshape(1, -1))
+            assert e < tol_g, (order, smax, i, int(S_b[i]), e)
+        for i in sorted({0, B // 2, B - 1}):
+            if S_b[i] > 64 and order == 5:
+                continue   # the dense oracle itself is ill-conditioned there
+            ref, _ = oracle_mod.solve(order, wps[i], bc[i, [0, 1]], bc[i, [2, 3]], tms[i], 0.0, float(vw[i]))
+            e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), ref.reshape(1, -1))
+            assert e < (1e-5 if order == 5 else 1e-7), (order, smax, i, e)
+    # uniform long trajectories, batch-wide boundary conditions, host-memory entry, fp64 and fp32 storage
+    for S in (17, 32, 100):
+        wp, tm = synth.make_batch(77, S, config_id=400 + order)
+        bc1 = rng.normal(size=(1, 4, 3))
+        r = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, want_status=True)
+        assert r.kernel == "chunked_o%d_f64_l%d" % (order, 8 if S <= 32 else 32), r.kernel
+        g = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, force_generic=True)
+        assert not r.status.any()
+        assert synth.rel_err(r.coeffs, g.coeffs) < tol_g, (order, S)
+        r32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05)
+        g32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05, force_generic=True)
+        assert r32.kernel.startswith("chunked_o%d_f32io_f64_l" % order), r32.kernel
+        assert r32.coeffs.dtype == np.float32
+        assert synth.rel_err(r32.coeffs, g32.coeffs) < 1e-6, (order, S)
+
+
+def test_chunked_kernel_status(csp):
+    wp, tm = synth.make_batch(70, 40, config_id=3)
+    tm[5, 3] = 0.0
+    tm[33, 39] = float("nan")
+    r = csp.solve_batch(wp, tm, order=4, want_status=True)
+    assert r.kernel.startswith("chunked_"), r.kernel
+    assert np.flatnonzero(r.status).tolist() == [5, 33]
+    good = np.setdiff1d(np.arange(70), [5, 33])
+    assert np.isfinite(r.coeffs[good]).all()
 
 
 def test_full_size_properties(csp):
