@@ -12,10 +12,10 @@
 //      the current factor: that yields the chunk's Schur complement onto its two interface waypoints
 //      (D_L, D_R symmetric, coupling E, right-hand sides r_L, r_R) without storing anything;
 //   2. the interface system -- block-tridiagonal again, nch-1 unknown waypoints -- sits in LDS
-//      (24 doubles per interface at order 4).  Every lane solves it for the two interfaces of its own
-//      chunk by a twisted elimination: Schur carries from the left end up to its left interface and
-//      from the right end down to its right interface, nch-1 block steps for every lane, so the
-//      loop is wave-uniform and needs no storage either;
+//      (24 doubles per interface at order 4).  Lane j solves interface j+1 by a twisted elimination:
+//      Schur carries from the left end up to interface j and from the right end down to j+2, nch-2
+//      block steps for every lane, so the loop is wave-uniform and needs no storage either; its left
+//      interface comes from lane j-1 through LDS;
 //   3. with all derivatives known at both ends the chunk is an independent little trajectory: a
 //      forward sweep keeping W_k, z_k in registers (<= 3 interior waypoints), back-substitution,
 //      Hermite -> monomial recovery (minimum_snap.cpp:582-591) and the stores.
@@ -185,10 +185,12 @@ template <int O> struct IfaceLds {
 };
 
 template <int O, typename IO>
-__global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(O <= 4 ? 2 : 1)))
+minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
     constexpr int N = O - 1, M = 2 * O;
     using IL = IfaceLds<O>;
     __shared__ double lds[IL::ENTRIES * 64];
+    __shared__ double xch[3 * N * 64];   // solved interface derivatives, handed to the right-hand neighbour
     const int lane = threadIdx.x;
     const int lpt = 1 << lpt_log2;
     const int j = lane & (lpt - 1);                                  // my chunk
@@ -209,29 +211,14 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
     const int64_t pt0 = seg0 + bb + s0, sg0 = seg0 + s0;
     const double vw = a.vw_per ? a.vw_per[bb] : a.vel_zero_weight;
 
-    // trajectory boundary derivatives (minimum_snap.cpp:527-555): v, a given, higher ones pinned to 0
-    double x0[N][3], xn[N][3];
-    {
-        const IO *bc = (const IO *)a.bc + (a.bc_per_traj ? bb * 12 : 0);
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                x0[r][ax] = r == 0 ? ld(bc + 0 * 3 + ax) : r == 1 ? ld(bc + 2 * 3 + ax) : 0.0;
-                xn[r][ax] = r == 0 ? ld(bc + 1 * 3 + ax) : r == 1 ? ld(bc + 3 * 3 + ax) : 0.0;
-            }
-    }
-
     bool spd = true;
     double T[CMAX], P[CMAX + 1][3];
     // ---- step 1: the chunk's Schur complement onto its two interfaces ----
     double DR[N][N], rR[N][3];
     {
         double DL[N][N], rL[N][3], Et[N][N], unused[N][N];
-        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
-        spd &= chunk_schur<O, true>(T, P, c, vw, DR, rR, Et);            // end row: DR x_R + Et x_L = rR
         load_chunk<IO, true>(wp, tm, pt0, sg0, c, T, P);
-        spd &= chunk_schur<O, false>(T, P, c, vw, DL, rL, unused);       // reversed frame: start row
+        spd &= chunk_schur<O, false>(T, P, c, vw, DL, rL, unused);       // reversed frame: the START interface row
         if (active) {
             int e = 0;
 #pragma unroll
@@ -242,10 +229,14 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
             for (int r = 0; r < N; ++r)
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) lds[(e++) * 64 + lane] = (r & 1) ? rL[r][ax] : -rL[r][ax];  // derivative r+1 is odd for even r
+        }
+        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
+        spd &= chunk_schur<O, true>(T, P, c, vw, DR, rR, Et);            // end row: DR x_R + Et x_L = rR
+        if (active) {
 #pragma unroll
             for (int r = 0; r < N; ++r)
 #pragma unroll
-                for (int qq = 0; qq < N; ++qq) lds[(e++) * 64 + lane] = Et[qq][r];                        // E = Et^T
+                for (int qq = 0; qq < N; ++qq) lds[(IL::OFF_E + r * N + qq) * 64 + lane] = Et[qq][r];       // E = Et^T
         }
     }
     __syncthreads();
@@ -263,22 +254,38 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
     }
     __syncthreads();
 
-    // ---- step 2: twisted elimination of the interface system; this lane wants x_jj and x_jj+1 ----
-    double xL[N][3], xR[N][3];
+    // trajectory boundary derivatives (minimum_snap.cpp:527-555): v, a given, higher ones pinned to 0
+    double x0[N][3], xn[N][3];
+    {
+        const IO *bc = (const IO *)a.bc + (a.bc_per_traj ? bb * 12 : 0);
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                x0[r][ax] = r == 0 ? ld(bc + 0 * 3 + ax) : r == 1 ? ld(bc + 2 * 3 + ax) : 0.0;
+                xn[r][ax] = r == 0 ? ld(bc + 1 * 3 + ax) : r == 1 ? ld(bc + 3 * 3 + ax) : 0.0;
+            }
+    }
+
+    // ---- step 2: twisted elimination of the interface system; lane j solves interface j+1 ----
+    // (its right end) from the Schur carry of interfaces 1..j on the left and nch-1..j+2 on the right,
+    // and takes its left end from lane j-1 through LDS.  nch-2 block steps for every lane.
+    double xR[N][3];
+    const bool solver = active && j + 1 < nch;
     {
         const int base = lane - j;
-        const int jj = (j < nch - 2) ? j : (nch - 2 > 0 ? nch - 2 : 0);
+        const int nst = solver ? nch - 2 : -1;   // steps of this lane (-1: takes no part)
         double cS[N][N], cr[N][3];     // current Schur carry onto the next interface
-        double lS[N][N], lr[N][3];     // the finished left carry (onto interface jj+1)
-        double Wf[N][N], zc[N][3], WL[N][N], zL[N][3], rinit[N][3];
+        double lS[N][N], lr[N][3];     // the finished left carry (onto interface j+1)
+        double rinit[N][3];
 #pragma unroll
         for (int r = 0; r < N; ++r) {
 #pragma unroll
-            for (int qq = 0; qq < N; ++qq) { cS[r][qq] = 0.0; lS[r][qq] = 0.0; Wf[r][qq] = 0.0; WL[r][qq] = 0.0; }
+            for (int qq = 0; qq < N; ++qq) { cS[r][qq] = 0.0; lS[r][qq] = 0.0; }
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) { cr[r][ax] = 0.0; lr[r][ax] = 0.0; zc[r][ax] = 0.0; zL[r][ax] = 0.0; rinit[r][ax] = 0.0; }
+            for (int ax = 0; ax < 3; ++ax) { cr[r][ax] = 0.0; lr[r][ax] = 0.0; rinit[r][ax] = 0.0; }
         }
-        if (active) {
+        if (solver) {
             // the known ends enter as right-hand sides: -E_0^T x_0 onto interface 1, -E_{nch-1} x_n onto nch-1
 #pragma unroll
             for (int r = 0; r < N; ++r)
@@ -293,19 +300,19 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
                     }
                 }
         }
-        for (int t = 0; __builtin_amdgcn_ballot_w64(t <= nch - 2) != 0; ++t) {
-            if (t == jj) {   // the left sweep has reached my left interface: keep its result, start from the right end
+        for (int t = 0; __builtin_amdgcn_ballot_w64(t <= nst) != 0; ++t) {
+            if (t == j) {   // the left sweep has reached my left interface: keep its carry, start from the right end
 #pragma unroll
                 for (int r = 0; r < N; ++r) {
 #pragma unroll
-                    for (int qq = 0; qq < N; ++qq) { lS[r][qq] = cS[r][qq]; WL[r][qq] = Wf[r][qq]; cS[r][qq] = 0.0; }
+                    for (int qq = 0; qq <= r; ++qq) { lS[r][qq] = cS[r][qq]; cS[r][qq] = 0.0; }
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) { lr[r][ax] = cr[r][ax]; zL[r][ax] = zc[r][ax]; cr[r][ax] = rinit[r][ax]; }
+                    for (int ax = 0; ax < 3; ++ax) { lr[r][ax] = cr[r][ax]; cr[r][ax] = rinit[r][ax]; }
                 }
             }
-            if (t < nch - 2) {
-                const bool isleft = t < jj;
-                const int i = isleft ? t + 1 : nch - 1 - (t - jj);
+            if (t < nst) {
+                const bool isleft = t < j;
+                const int i = isleft ? t + 1 : nch - 1 - (t - j);
                 const int slotD = base + i, slotE = base + (isleft ? i : i - 1);
                 const int sr = isleft ? N : 1, sc = isleft ? 1 : N;   // F = E_i (left) or E_{i-1}^T (right)
                 double Sm[N][N], R[N][N + 3], F[N][N];
@@ -322,41 +329,33 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
                 for (int r = 0; r < N; ++r)
 #pragma unroll
                     for (int qq = 0; qq < N; ++qq) { F[r][qq] = lds[(IL::OFF_E + r * sr + qq * sc) * 64 + slotE]; R[r][qq] = F[r][qq]; }
-                spd &= SmallSpd<N, N + 3>::solve(Sm, R);
-#pragma unroll
-                for (int r = 0; r < N; ++r) {
-#pragma unroll
-                    for (int qq = 0; qq < N; ++qq) Wf[r][qq] = R[r][qq];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) zc[r][ax] = R[r][N + ax];
-                }
+                spd &= SmallSpd<N, N + 3>::solve(Sm, R);   // R = S^-1 [F | rhs]
 #pragma unroll
                 for (int r = 0; r < N; ++r) {
 #pragma unroll
                     for (int qq = 0; qq <= r; ++qq) {
                         double v = 0.0;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], Wf[k][qq], v);
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], R[k][qq], v);
                         cS[r][qq] = v;
                     }
 #pragma unroll
                     for (int ax = 0; ax < 3; ++ax) {
                         double v = 0.0;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], zc[k][ax], v);
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], R[k][N + ax], v);
                         cr[r][ax] = v;
                     }
                 }
             }
         }
-        // both carries now sit on interface jj+1; x_jj follows from the last left step
-        double xa[N][3], xb[N][3];
+        // both carries now sit on interface j+1
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) { xa[r][ax] = x0[r][ax]; xb[r][ax] = xn[r][ax]; }
-        if (active && nch >= 2) {
-            const int slotD = base + jj + 1;
+            for (int ax = 0; ax < 3; ++ax) xR[r][ax] = xn[r][ax];
+        if (solver) {
+            const int slotD = base + j + 1;
             double Sm[N][N], R[N][3];
             int e = 0;
 #pragma unroll
@@ -372,29 +371,17 @@ __global__ void __launch_bounds__(64) minsnap_chunked_kernel(GenericArgs a, int 
             for (int r = 0; r < N; ++r)
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
-                    xb[r][ax] = R[r][ax];
+                    xR[r][ax] = R[r][ax];
+                    xch[(r * 3 + ax) * 64 + lane] = R[r][ax];
                 }
-            if (jj >= 1) {
-#pragma unroll
-                for (int r = 0; r < N; ++r)
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        double v = zL[r][ax];
-#pragma unroll
-                        for (int k = 0; k < N; ++k) v = __builtin_fma(-WL[r][k], R[k][ax], v);
-                        xa[r][ax] = v;
-                    }
-            }
         }
-        const bool last = (nch >= 2) && (j == nch - 1);   // the last chunk rode along with its left neighbour
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                xL[r][ax] = last ? xb[r][ax] : xa[r][ax];
-                xR[r][ax] = last ? xn[r][ax] : xb[r][ax];
-            }
     }
+    __syncthreads();
+    double xL[N][3];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) xL[r][ax] = (active && j >= 1) ? xch[(r * 3 + ax) * 64 + lane - 1] : x0[r][ax];
 
     // ---- step 3: the chunk as a little trajectory with every derivative known at both ends ----
     double nanacc = 0.0;
