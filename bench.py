@@ -51,35 +51,43 @@ def cpu_baseline(order, S, wp, tm, budget_s):
                       "(oracle/dense_oracle.c, -O2, OpenMP), %.1f s" % (n, wp.shape[0], dt)}, ref, n
 
 
+def _load_mixed(csp):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("csp_mixed", os.path.join(os.path.dirname(csp.__file__), "mixed.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 def bench_c5(args, csp, dev):
     """Side benchmark (not the driver's line): BASELINE config C5 -- mixed batch, S ~ U{4..64},
-    order ~ U{3,4,5}, fp32 storage, bucketed by order and sorted by S on the host BEFORE the timed
-    region; one ragged call per order."""
+    order ~ U{3,4,5}, fp32 storage, bucketed by order and length class on the host BEFORE the timed
+    region; one ragged call per bucket."""
     trajs = synth.make_ragged(args.batch)
     buckets = []
     total_bytes = 0
+    mixed = _load_mixed(csp)
     for order in (3, 4, 5):
         sel = sorted((t for t in trajs if t[0] == order), key=lambda t: len(t[2]))
-        wp = torch.from_numpy(np.concatenate([t[1] for t in sel]).astype(np.float32)).to(dev)
-        tm = torch.from_numpy(np.concatenate([t[2] for t in sel]).astype(np.float32)).to(dev)
-        lens = np.array([len(t[2]) for t in sel])
-        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev)
-        out = torch.empty((int(lens.sum()), 3, 2 * order), dtype=torch.float32, device=dev)
-        desc = csp.make_desc(order, len(sel), 0, csp.DTYPE_F32, mem_space=csp.MEM_DEVICE, seg_offsets_ptr=off.data_ptr(),
-                             max_segments=int(lens.max()))
-        ws = torch.empty(max(csp.workspace_bytes(desc), 1), dtype=torch.uint8, device=dev)
-        buckets.append((order, wp, tm, off, out, ws, int(lens.max())))
-        total_bytes += sum(synth.algorithmic_bytes(int(n), order, 4) for n in lens)
+        all_lens = np.array([len(t[2]) for t in sel])
+        for lo, hi in mixed.length_classes(all_lens):   # one ragged call per power-of-two length class
+            sub, lens = sel[lo:hi], all_lens[lo:hi]
+            wp = torch.from_numpy(np.concatenate([t[1] for t in sub]).astype(np.float32)).to(dev)
+            tm = torch.from_numpy(np.concatenate([t[2] for t in sub]).astype(np.float32)).to(dev)
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev)
+            buckets.append(csp.PreparedSolve(wp, tm, order=order, seg_offsets=off, max_segments=int(lens.max())))
+            total_bytes += sum(synth.algorithmic_bytes(int(n), order, 4) for n in lens)
 
-    # one HIP stream per order bucket: a bucket alone (~22k lanes) cannot fill 1024 SIMDs
-    streams = [torch.cuda.Stream(device=dev) for _ in buckets]
+    # a bucket alone cannot fill 1024 SIMDs: four HIP streams, buckets dealt round-robin, longest first
+    buckets.sort(key=lambda ps: -ps.tm.numel())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(min(4, len(buckets)))]
     main = torch.cuda.current_stream(dev)
 
     def step():
-        for st_, (order, wp, tm, off, out, ws, smax) in zip(streams, buckets):
+        for st_ in streams:
             st_.wait_stream(main)
-            csp.solve_batch(wp, tm, order=order, seg_offsets=off, max_segments=smax, out=out, workspace=ws,
-                            stream=st_.cuda_stream)
+        for i, ps in enumerate(buckets):
+            ps.run(streams[i % len(streams)].cuda_stream)
         for st_ in streams:
             main.wait_stream(st_)
     for _ in range(args.warmup):

@@ -279,21 +279,34 @@ class PreparedSolve:
     building the descriptor and checking tensors costs more host time than a 40-us kernel."""
 
     def __init__(self, waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0, out=None,
-                 force_generic=False, segment_major=False, no_persistent=False, stream=None):
+                 force_generic=False, segment_major=False, no_persistent=False, stream=None,
+                 seg_offsets=None, max_segments=None):
         import torch
         if not (_is_torch(waypoints) and waypoints.is_cuda):
             raise ValueError("PreparedSolve takes CUDA tensors (device memory space)")
         self.dev, tdt = waypoints.device, waypoints.dtype
         dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
         self.wp, self.tm = waypoints.contiguous(), times.to(tdt).contiguous()
-        B, S = self.tm.shape
+        ragged = seg_offsets is not None
         m = 2 * int(order)
+        if ragged:   # concatenated trajectories: waypoints [sum(S_b)+B,3], times [sum S_b], offsets [B+1] on the device
+            if segment_major:
+                raise ValueError("segment_major needs a uniform batch")
+            self.off = seg_offsets.to(device=self.dev, dtype=torch.int64).contiguous()
+            B, S = self.off.numel() - 1, 0
+            total = self.tm.numel()
+            if max_segments is None:
+                max_segments = int((self.off[1:] - self.off[:-1]).max().item()) if B else 1
+        else:
+            B, S = self.tm.shape
         self.bc = (torch.zeros((1, 4, 3), dtype=tdt, device=self.dev) if bc is None
                    else bc.to(tdt).contiguous().reshape(-1, 4, 3))
-        self.out = out if out is not None else torch.empty((S, B, 3, m) if segment_major else (B, S, 3, m), dtype=tdt, device=self.dev)
+        shape = (total, 3, m) if ragged else ((S, B, 3, m) if segment_major else (B, S, 3, m))
+        self.out = out if out is not None else torch.empty(shape, dtype=tdt, device=self.dev)
         flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
                  | (FLAG_NO_PERSISTENT if no_persistent else 0))
         self.desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, self.bc.shape[0] == B and B != 1,
+                              seg_offsets_ptr=self.off.data_ptr() if ragged else None, max_segments=(max_segments or 0) if ragged else 0,
                               device_id=self.dev.index if self.dev.index is not None else -1, flags=flags)
         self.ws_bytes = workspace_bytes(self.desc)
         self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.dev)

@@ -127,7 +127,9 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.skip = skip;
     // the fixed kernel moves 16-byte pieces (LDS-DMA, ds_read_b128, dwordx4 stores)
     const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
-    if ((use_fixed(d, s) || use_chunked(d, s)) && !aligned) return CSP_ERR_INVALID_ARG;
+    if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;
+    // the chunked kernel reads scalars and stores 16-byte pieces (8-byte for fp32 with odd order)
+    if (use_chunked(d, s) && ((uintptr_t)co & ((s.f32 && (s.order & 1)) ? 7u : 15u))) return CSP_ERR_INVALID_ARG;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st)
                  : use_chunked(d, s) ? csp::launch_chunked(a, s.f32, s.Smax, st)
                                      : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);

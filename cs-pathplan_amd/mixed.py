@@ -1,10 +1,27 @@
 """Host-side bucketing for mixed batches (BASELINE config C5: per-trajectory segment count and
 order).  One C-ABI call serves one derivative order; inside a call trajectories are ragged.
-Trajectories are grouped by order and sorted by segment count, so the 64 lanes of a wave run
-loops of similar length."""
+Trajectories are grouped by order, sorted by segment count and cut into power-of-two length classes
+(one ragged call each), so the lanes of a wave run loops of similar length."""
 import importlib
 
 import numpy as np
+
+# The workspace-free ragged kernel gives every trajectory of a call the same number of lanes, chosen
+# from the call's longest trajectory (4 segments per lane): one call per power-of-two length class
+# keeps the lanes of short trajectories busy.
+LENGTH_CLASSES = (4, 8, 16, 32, 64, 128, 256)
+
+
+def length_classes(sorted_lens):
+    """sorted_lens: ascending segment counts.  Returns [(lo, hi)] index ranges, one per non-empty class."""
+    sorted_lens = np.asarray(sorted_lens)
+    out, lo = [], 0
+    for cap in LENGTH_CLASSES + (None,):
+        hi = len(sorted_lens) if cap is None else int(np.searchsorted(sorted_lens, cap, side="right"))
+        if hi > lo:
+            out.append((lo, hi))
+        lo = hi
+    return out
 
 
 def solve_mixed(trajs, dtype=np.float32, f32_arith=False, device=None):
@@ -16,19 +33,22 @@ def solve_mixed(trajs, dtype=np.float32, f32_arith=False, device=None):
     for order in sorted({t[0] for t in trajs}):
         idx = [i for i, t in enumerate(trajs) if t[0] == order]
         idx.sort(key=lambda i: len(trajs[i][2]))
-        wp = np.concatenate([np.asarray(trajs[i][1]) for i in idx]).astype(dtype)
-        tm = np.concatenate([np.asarray(trajs[i][2]) for i in idx]).astype(dtype)
-        off = np.concatenate([[0], np.cumsum([len(trajs[i][2]) for i in idx])]).astype(np.int64)
-        if device is not None:
-            import torch
-            r = csp.solve_batch(torch.from_numpy(wp).to(device), torch.from_numpy(tm).to(device), order=order,
-                                seg_offsets=torch.from_numpy(off).to(device), max_segments=int(np.max(np.diff(off))),
-                                f32_arith=f32_arith)
-            co = r.coeffs.cpu().numpy()
-        else:
-            r = csp.solve_batch(wp, tm, order=order, seg_offsets=off, f32_arith=f32_arith)
-            co = r.coeffs
-        kernels.append(r.kernel)
-        for j, i in enumerate(idx):
-            out[i] = co[off[j]:off[j + 1]]
+        lens = np.array([len(trajs[i][2]) for i in idx])
+        for lo, hi in length_classes(lens):
+            sub = idx[lo:hi]
+            wp = np.concatenate([np.asarray(trajs[i][1]) for i in sub]).astype(dtype)
+            tm = np.concatenate([np.asarray(trajs[i][2]) for i in sub]).astype(dtype)
+            off = np.concatenate([[0], np.cumsum(lens[lo:hi])]).astype(np.int64)
+            if device is not None:
+                import torch
+                r = csp.solve_batch(torch.from_numpy(wp).to(device), torch.from_numpy(tm).to(device), order=order,
+                                    seg_offsets=torch.from_numpy(off).to(device), max_segments=int(lens[hi - 1]),
+                                    f32_arith=f32_arith)
+                co = r.coeffs.cpu().numpy()
+            else:
+                r = csp.solve_batch(wp, tm, order=order, seg_offsets=off, f32_arith=f32_arith)
+                co = r.coeffs
+            kernels.append(r.kernel)
+            for j, i in enumerate(sub):
+                out[i] = co[off[j]:off[j + 1]]
     return out, kernels
