@@ -421,9 +421,11 @@ def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, 
     return r
 
 
-def sample_batch(times, coeffs, sample_distance, capacity, order=None):
+def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None):
     """Batched sampling half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:97-205).
-    times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2])."""
+    times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2]).
+    `out` (device path): a (samples, counts, stats) triple to reuse; rows beyond counts[b] are then
+    left as they were instead of zero."""
     on_device = _is_torch(times)
     B, S = times.shape
     order = int(order) if order is not None else int(coeffs.shape[-1]) // 2
@@ -432,9 +434,12 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None):
         dev, tdt = times.device, times.dtype
         dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
         times, coeffs = times.contiguous(), coeffs.to(tdt).contiguous()
-        samples = torch.zeros((B, capacity, 3), dtype=tdt, device=dev)
-        counts = torch.empty(B, dtype=torch.int32, device=dev)
-        stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
+        if out is not None:
+            samples, counts, stats = out
+        else:
+            samples = torch.zeros((B, capacity, 3), dtype=tdt, device=dev)
+            counts = torch.empty(B, dtype=torch.int32, device=dev)
+            stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
         desc = make_desc(order, B, S, dtype, mem_space=MEM_DEVICE, device_id=dev.index if dev.index is not None else -1)
         st = torch.cuda.current_stream(dev).cuda_stream
         _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.data_ptr(), coeffs.data_ptr(), float(sample_distance),

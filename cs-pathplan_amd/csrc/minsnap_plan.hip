@@ -51,8 +51,8 @@ hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *ite
     return hipGetLastError();
 }
 
-template <int M, typename IO>
-__device__ __forceinline__ void eval_poly(const IO *rec, double t, double (&out)[3]) {
+template <int M>
+__device__ __forceinline__ void eval_poly(const double (&c)[3][M], double t, double (&out)[3]) {
     // sum of c_k * t^(M-1-k), k ascending, like the reference's eval lambda (:104-117)
     double pw[M];
     pw[M - 1] = 1.0;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void eval_poly(const IO *rec, double t, double (&out)
     for (int a = 0; a < 3; ++a) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < M; ++k) v += (double)rec[a * M + k] * pw[k];
+        for (int k = 0; k < M; ++k) v += c[a][k] * pw[k];
         out[a] = v;
     }
 }
@@ -109,13 +109,18 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
     double prev[3], cur[3];
     for (int seg = 0; seg < S; ++seg) {
         const IO *rec = co + (int64_t)seg * seg_stride;
+        double c[3][M];   // the segment's record, read ONCE (the evaluations below run from registers)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int k = 0; k < M; ++k) c[ax][k] = (double)rec[ax * M + k];
         const double T = (double)tm[seg];
         double dt = 0.1;
         if (dt > T / 10.0) dt = T / 10.0;  // at least 10 evaluations per segment (:126)
-        eval_poly<M, IO>(rec, 0.0, prev);
+        eval_poly<M>(c, 0.0, prev);
         if (n == 0) record(prev);
         for (double t = dt; t <= T + 1e-12; t += dt) {  // accumulated like the reference (:140)
-            eval_poly<M, IO>(rec, t < T ? t : T, cur);
+            eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
             if (sqrt(dx * dx + dy * dy + dz * dz) >= a.sample_distance) {
                 prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
             }
         }
         if (seg == S - 1) {  // make sure the end point is present, without duplicating it (:157-160)
-            eval_poly<M, IO>(rec, T, cur);
+            eval_poly<M>(c, T, cur);
             const double dx = p1[0] - cur[0], dy = p1[1] - cur[1], dz = p1[2] - cur[2];
             if (n == 0 || sqrt(dx * dx + dy * dy + dz * dz) > 1e-6) record(cur);
         }
