@@ -421,11 +421,11 @@ def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, 
     return r
 
 
-def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None):
+def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None, one_lane=False):
     """Batched sampling half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:97-205).
     times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2]).
     `out` (device path): a (samples, counts, stats) triple to reuse; rows beyond counts[b] are then
-    left as they were instead of zero."""
+    left as they were instead of zero.  `one_lane` forces the one-lane-per-trajectory kernel (A/B tests)."""
     on_device = _is_torch(times)
     B, S = times.shape
     order = int(order) if order is not None else int(coeffs.shape[-1]) // 2
@@ -440,7 +440,8 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None)
             samples = torch.zeros((B, capacity, 3), dtype=tdt, device=dev)
             counts = torch.empty(B, dtype=torch.int32, device=dev)
             stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
-        desc = make_desc(order, B, S, dtype, mem_space=MEM_DEVICE, device_id=dev.index if dev.index is not None else -1)
+        desc = make_desc(order, B, S, dtype, mem_space=MEM_DEVICE, device_id=dev.index if dev.index is not None else -1,
+                         flags=FLAG_FORCE_GENERIC if one_lane else 0)
         st = torch.cuda.current_stream(dev).cuda_stream
         _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.data_ptr(), coeffs.data_ptr(), float(sample_distance),
                                              int(capacity), samples.data_ptr(), counts.data_ptr(), stats.data_ptr(),
@@ -454,7 +455,7 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None)
     samples = np.zeros((B, capacity, 3), dtype=npdt)
     counts = np.empty(B, dtype=np.int32)
     stats = np.empty((B, 2), dtype=np.float64)
-    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST)
+    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST, flags=FLAG_FORCE_GENERIC if one_lane else 0)
     _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.ctypes.data, coeffs.ctypes.data, float(sample_distance),
                                          int(capacity), samples.ctypes.data, counts.ctypes.data, stats.ctypes.data, None))
     return samples, counts, stats

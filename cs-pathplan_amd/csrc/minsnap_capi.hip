@@ -401,6 +401,8 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     csp::SampleArgs a;
     a.B = s.B; a.S = s.S; a.order = s.order; a.capacity = capacity; a.sample_distance = sample_distance;
     a.seg_major = (desc->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
+    a.Smax = s.Smax;
+    a.one_lane = (desc->flags & CSP_FLAG_FORCE_GENERIC) ? 1 : 0;
     if (desc->mem_space == CSP_MEM_DEVICE) {
         a.times = times; a.coeffs = coeffs; a.seg_off = s.ragged ? desc->seg_offsets : nullptr;
         a.samples = samples; a.counts = counts; a.stats = stats;

@@ -70,6 +70,8 @@ struct SampleArgs {
     double *stats;      // [B][2] max climb rate, min turn radius (or null)
     int64_t B, capacity;
     int S, order, seg_major;
+    int Smax;           // longest trajectory (uniform: S)
+    int one_lane;       // force the one-lane-per-trajectory kernel (CSP_FLAG_FORCE_GENERIC)
     double sample_distance;
 };
 hipError_t launch_sample(const SampleArgs &a, bool f32, hipStream_t st);

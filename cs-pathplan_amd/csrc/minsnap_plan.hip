@@ -4,7 +4,8 @@
 //     10 increases, vel_zero_weight <- (w < 1e-6 ? 0.01 : 2w);
 //   * polynomial sampling at dt = min(0.1, T/10) with sequential distance thinning, the end-point
 //     rule and the climb-rate / turn-radius statistics (:97-195).
-// One lane per trajectory: both are inherently sequential per trajectory.
+// The loop bookkeeping is one lane per trajectory; sampling runs one lane per (trajectory, segment)
+// for trajectories of up to 64 segments and one lane per trajectory beyond.
 #include "minsnap_launch.h"
 
 namespace csp {
@@ -137,7 +138,256 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
     if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Segment-parallel sampler (trajectories of <= 64 segments): one lane per (trajectory, segment).
+// What makes that legal: the reference restarts its thinning reference point at every segment
+// (`prev = eval(0)`, :128-133), so which candidates a segment keeps does not depend on the other
+// segments.  What does cross segments is (a) the output position = number of samples recorded
+// before, (b) the two most recently recorded samples, which the climb-rate / turn-radius statistics
+// of a segment's first samples and the end-point rule look at.  So:
+//   pass 1  every lane evaluates and thins its segment without storing: count, last two kept samples;
+//   exchange: prefix sum of the counts over the trajectory's lanes, the two most recent samples
+//           recorded before each segment (backward scan), the end-point decision of the last segment;
+//   pass 2  the same evaluation and thinning again, now storing at the known offset.
+// The statistics (:167-193) are a function of consecutive recorded samples only.  With fp64 storage
+// the stored samples ARE the recorded values, so a second kernel (sample_stats_kernel: one wave per
+// trajectory, coalesced reads, max/min reductions) computes them from the sample array; a trajectory
+// that overflows `capacity` (samples beyond it are not stored) and fp32 storage (stored values are
+// rounded) take them inline in pass 2 instead, like the one-lane kernel.  The arithmetic per
+// candidate and per recorded sample is the one-lane kernel's: identical samples, counts, statistics.
+struct SampleStats {
+    double p0[3], p1[3];   // the two most recently recorded samples
+    double max_climb, min_r;
+    int64_t n;
+    // statistics of the sample about to become number n (:167-193)
+    __device__ __forceinline__ void look(const double (&p)[3]) {
+        if (n >= 1) {
+            const double dx = p[0] - p1[0], dy = p[1] - p1[1], dz = fabs(p[2] - p1[2]);
+            const double hd = sqrt(dx * dx + dy * dy);
+            if (hd > 1e-6) { const double r = dz / hd; if (r > max_climb) max_climb = r; }
+            if (n >= 2) {
+                const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                const double w[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
+                const double la = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+                const double lb = sqrt(dx * dx + dy * dy + (p[2] - p1[2]) * (p[2] - p1[2]));
+                const double lc = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
+                const double area = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
+                if (area > 1e-8) { const double R = la * lb * lc / (4.0 * area); if (R < min_r) min_r = R; }
+            }
+        }
+    }
+    __device__ __forceinline__ void shift(const double (&p)[3]) {
+        p0[0] = p1[0]; p0[1] = p1[1]; p0[2] = p1[2];
+        p1[0] = p[0]; p1[1] = p[1]; p1[2] = p[2];
+        ++n;
+    }
+};
+
+template <int O, typename IO>
+__global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_log2) {
+    constexpr int M = 2 * O;
+    constexpr bool F64 = sizeof(IO) == 8;
+    __shared__ double l_last[6 * 64];
+    __shared__ int l_cnt[64];
+    const int lane = threadIdx.x;
+    const int lpt = 1 << lpt_log2;
+    const int j = lane & (lpt - 1);
+    const int base = lane - j;
+    const int64_t b = ((int64_t)blockIdx.x * 64 + lane) >> lpt_log2;
+    const bool traj_ok = b < a.B;
+    const int64_t bb = traj_ok ? b : a.B - 1;
+    int64_t seg0;
+    int S;
+    if (a.seg_off) { seg0 = a.seg_off[bb]; S = (int)(a.seg_off[bb + 1] - seg0); }
+    else { seg0 = bb * (int64_t)a.S; S = a.S; }
+    if (!traj_ok) S = 0;
+    const bool active = j < S;
+    const int sj = active ? j : 0;
+    const IO *rec;
+    if (a.seg_major && !a.seg_off) rec = (const IO *)a.coeffs + ((int64_t)sj * a.B + bb) * 3 * M;
+    else rec = (const IO *)a.coeffs + (seg0 + sj) * 3 * M;
+    double c[3][M];
+    double T = 1.0;
+    if (active) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int k = 0; k < M; ++k) c[ax][k] = (double)rec[ax * M + k];
+        T = (double)((const IO *)a.times)[seg0 + sj];
+    } else {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int k = 0; k < M; ++k) c[ax][k] = 0.0;
+    }
+    double dt = 0.1;
+    if (dt > T / 10.0) dt = T / 10.0;   // at least 10 evaluations per segment (:126)
+    const double sd = a.sample_distance;
+
+    // ---- pass 1: which candidates does this segment keep? ----
+    int cnt = 0;
+    double l1[3] = {0, 0, 0}, l2[3] = {0, 0, 0};   // last / second-to-last kept sample of this segment
+    if (active) {
+        double prev[3], cur[3];
+        eval_poly<M>(c, 0.0, prev);
+        if (j == 0) { cnt = 1; l1[0] = prev[0]; l1[1] = prev[1]; l1[2] = prev[2]; }   // the very first sample (n == 0)
+        for (double t = dt; t <= T + 1e-12; t += dt) {
+            eval_poly<M>(c, t < T ? t : T, cur);
+            const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+            if (sqrt(dx * dx + dy * dy + dz * dz) >= sd) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { prev[q] = cur[q]; l2[q] = l1[q]; l1[q] = cur[q]; }
+                ++cnt;
+            }
+        }
+    }
+    l_cnt[lane] = cnt;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { l_last[q * 64 + lane] = l1[q]; l_last[(3 + q) * 64 + lane] = l2[q]; }
+    __syncthreads();
+
+    // ---- exchange: samples recorded before my segment, and the two most recent of them ----
+    int nbefore;
+    {
+        int incl = cnt;   // inclusive prefix sum over the trajectory's lanes
+        for (int d = 1; d < lpt; d <<= 1) {
+            const int o = __shfl_up(incl, d, lpt);
+            if (j >= d) incl += o;
+        }
+        nbefore = incl - cnt;
+    }
+    SampleStats st;
+    st.max_climb = 0.0;
+    st.min_r = 1.0e12;
+    st.n = nbefore;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { st.p0[q] = 0.0; st.p1[q] = 0.0; }
+    {
+        int have = 0;
+        for (int i = j - 1; i >= 0 && have < 2; --i) {
+            const int ci = l_cnt[base + i];
+            if (ci >= 1) {
+                if (have == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) st.p1[q] = l_last[q * 64 + base + i];
+                    have = 1;
+                    if (ci >= 2) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) st.p0[q] = l_last[(3 + q) * 64 + base + i];
+                        have = 2;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) st.p0[q] = l_last[q * 64 + base + i];
+                    have = 2;
+                }
+            }
+        }
+    }
+    // end-point rule of the last segment (:157-160): present unless it duplicates the last recorded sample
+    bool add_end = false;
+    double pend[3] = {0, 0, 0};
+    if (active && j == S - 1) {
+        eval_poly<M>(c, T, pend);
+        const double *pl = cnt >= 1 ? l1 : st.p1;
+        const double dx = pl[0] - pend[0], dy = pl[1] - pend[1], dz = pl[2] - pend[2];
+        add_end = (nbefore + cnt == 0) || sqrt(dx * dx + dy * dy + dz * dz) > 1e-6;
+    }
+    // the trajectory's total, known to its last lane, to every lane: does it fit `capacity`?
+    __syncthreads();
+    if (active && j == S - 1) l_cnt[base] = nbefore + cnt + (add_end ? 1 : 0);
+    __syncthreads();
+    const int traj_total = S > 0 ? l_cnt[base] : 0;
+    const bool inline_stats = !F64 || traj_total > a.capacity || a.stats == nullptr;
+
+    // ---- pass 2: evaluate and thin again, now storing ----
+    IO *out = (IO *)a.samples + bb * a.capacity * 3;
+    auto record = [&](const double (&p)[3]) {
+        if (st.n < a.capacity) { out[st.n * 3] = (IO)p[0]; out[st.n * 3 + 1] = (IO)p[1]; out[st.n * 3 + 2] = (IO)p[2]; }
+        if (inline_stats) st.look(p);
+        st.shift(p);
+    };
+    if (active) {
+        double prev[3], cur[3];
+        eval_poly<M>(c, 0.0, prev);
+        if (j == 0) record(prev);
+        for (double t = dt; t <= T + 1e-12; t += dt) {
+            eval_poly<M>(c, t < T ? t : T, cur);
+            const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+            if (sqrt(dx * dx + dy * dy + dz * dz) >= sd) {
+                prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+                record(cur);
+            }
+        }
+        if (add_end) record(pend);
+    }
+    // ---- per-trajectory results: max / min over the lanes ----
+    double max_climb = st.max_climb, min_r = st.min_r;
+    for (int d = 1; d < lpt; d <<= 1) {
+        const double oc = __shfl_xor(max_climb, d, 64), orr = __shfl_xor(min_r, d, 64);
+        max_climb = oc > max_climb ? oc : max_climb;
+        min_r = orr < min_r ? orr : min_r;
+    }
+    if (traj_ok && (S == 0 ? j == 0 : j == S - 1)) {
+        a.counts[b] = (int32_t)st.n;
+        // (0, 1e12) when the statistics are left to sample_stats_kernel
+        if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+    }
+}
+
+// Statistics from the stored samples (fp64 storage, trajectories that fit `capacity`): one wave per
+// trajectory, lane i looks at samples i-2, i-1, i.
+__global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples, const int32_t *counts, double *stats,
+                                                           int64_t B, int64_t capacity) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int n = counts[b];
+    if (n > capacity) return;   // taken inline by sample_seg_kernel
+    const double *row = samples + b * capacity * 3;
+    SampleStats st;
+    st.max_climb = 0.0;
+    st.min_r = 1.0e12;
+    for (int i = lane; i < n; i += 64) {
+        double p[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            p[q] = row[i * 3 + q];
+            st.p1[q] = i >= 1 ? row[(i - 1) * 3 + q] : 0.0;
+            st.p0[q] = i >= 2 ? row[(i - 2) * 3 + q] : 0.0;
+        }
+        st.n = i;
+        st.look(p);
+    }
+    double max_climb = st.max_climb, min_r = st.min_r;
+    for (int d = 1; d < 64; d <<= 1) {
+        const double oc = __shfl_xor(max_climb, d, 64), orr = __shfl_xor(min_r, d, 64);
+        max_climb = oc > max_climb ? oc : max_climb;
+        min_r = orr < min_r ? orr : min_r;
+    }
+    if (lane == 0) { stats[b * 2] = max_climb; stats[b * 2 + 1] = min_r; }
+}
+
 template <typename IO> static hipError_t launch_sample_t(const SampleArgs &a, hipStream_t st) {
+    if (a.Smax >= 1 && a.Smax <= 64 && !a.one_lane) {   // one lane per (trajectory, segment)
+        int l = 0;
+        while ((1 << l) < a.Smax) ++l;
+        const int64_t lanes = a.B << l;
+        const dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
+        switch (a.order) {
+            case 1: hipLaunchKernelGGL((sample_seg_kernel<1, IO>), grid, block, 0, st, a, l); break;
+            case 2: hipLaunchKernelGGL((sample_seg_kernel<2, IO>), grid, block, 0, st, a, l); break;
+            case 3: hipLaunchKernelGGL((sample_seg_kernel<3, IO>), grid, block, 0, st, a, l); break;
+            case 4: hipLaunchKernelGGL((sample_seg_kernel<4, IO>), grid, block, 0, st, a, l); break;
+            case 5: hipLaunchKernelGGL((sample_seg_kernel<5, IO>), grid, block, 0, st, a, l); break;
+            default: return hipErrorInvalidValue;
+        }
+        if (sizeof(IO) == 8 && a.stats)
+            hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, st, (const double *)a.samples,
+                               a.counts, a.stats, a.B, a.capacity);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((a.B + 63) / 64)), block(64);
     switch (a.order) {
         case 1: hipLaunchKernelGGL((sample_kernel<1, IO>), grid, block, 0, st, a); break;

@@ -396,6 +396,43 @@ def test_full_size_properties(csp):
     assert np.max(np.abs(r2 - exp)) < 1e-9 * np.max(np.abs(exp))
 
 
+@pytest.mark.parametrize("order,S,B", [(4, 64, 16384), (3, 37, 20000), (4, 200, 2048)])
+def test_long_trajectory_properties_at_scale(csp, order, S, B):
+    """The chunked kernel on batches of thousands of waves: interpolation, continuity of the 2(o-1)
+    derivatives the optimum leaves continuous at interior waypoints (chunk interfaces included),
+    boundary conditions, axis permutation -- no oracle involved."""
+    import torch
+    m = 2 * order
+    wp, tm = synth.make_batch(B, S, config_id=11)
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    r = csp.solve_batch(d_wp, d_tm, order=order, want_status=True)
+    assert r.kernel.startswith("chunked_o%d_f64" % order), r.kernel
+    c = r.coeffs.cpu().numpy()
+    assert not r.status.cpu().numpy().any()
+    T = tm[:, :, None]
+    pw = np.arange(m - 1, -1, -1)
+
+    def deriv_at(coef, t, j):
+        fac = np.array([np.prod(np.arange(p, p - j, -1)) if p >= j else 0.0 for p in pw])
+        e = np.clip(pw - j, 0, None)
+        return np.sum(coef * fac * t[..., None] ** e, axis=-1)
+
+    assert np.max(np.abs(c[..., m - 1] - wp[:, :-1, :])) == 0.0
+    scale = np.max(np.abs(wp))
+    assert np.max(np.abs(deriv_at(c, np.broadcast_to(T, c.shape[:3]), 0) - wp[:, 1:, :])) < 1e-9 * scale
+    for j in range(1, 2 * order - 1):
+        end = deriv_at(c[:, :-1], np.broadcast_to(T[:, :-1], c[:, :-1].shape[:3]), j)
+        start = deriv_at(c[:, 1:], np.zeros(c[:, 1:].shape[:3]), j)
+        mag = np.maximum(np.max(np.abs(start)), 1.0)
+        assert np.max(np.abs(end - start)) < (1e-9 if j < order else 1e-5) * mag, j
+    for j in range(1, order):
+        assert np.max(np.abs(deriv_at(c[:, 0], np.zeros((B, 3)), j))) < 1e-12
+        assert np.max(np.abs(deriv_at(c[:, -1], np.broadcast_to(T[:, -1], (B, 3)), j))) < 1e-7
+    perm = torch.from_numpy(np.ascontiguousarray(wp[:, :, [2, 0, 1]])).cuda()
+    rp = csp.solve_batch(perm, d_tm, order=order).coeffs.cpu().numpy()
+    assert np.array_equal(rp, c[:, :, [2, 0, 1], :])
+
+
 def test_time_alloc(csp, oracle_mod):
     wp, _ = synth.make_batch(300, 16, config_id=3)
     for (v, mt) in [(5.0, 0.1), (200.0, 1.0), (0.0, 0.7)]:

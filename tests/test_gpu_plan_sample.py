@@ -65,3 +65,23 @@ def test_device_memory_plan_and_sample(csp, oracle_mod):
         n = int(counts[b])
         assert n == len(ref)
         assert np.max(np.abs(samples[b, :n].cpu().numpy() - ref)) < 1e-7 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("order,S,B,sd", [(4, 16, 1000, 0.7), (3, 1, 200, 0.3), (2, 7, 333, 5.0), (5, 8, 100, 0.05),
+                                           (4, 64, 70, 1.5), (3, 37, 129, 100.0), (4, 2, 65, 1e-9)])
+def test_segment_parallel_sampler_is_bitwise_the_one_lane_sampler(csp, order, S, B, sd):
+    """Trajectories of up to 64 segments are sampled with one lane per (trajectory, segment) (two
+    passes, prefix sums over the segments); the result -- samples, counts, statistics -- must be
+    IDENTICAL to the sequential one-lane-per-trajectory kernel, which the oracle tests pin.  Covers
+    segments that keep nothing (large distance), capacity overflow and the end-point rule."""
+    import torch
+    wp, _ = synth.make_batch(B, S, config_id=24)
+    plan = csp.plan_batch(torch.from_numpy(wp * 3.0).cuda(), 5.0, 0.1, order=order)
+    for cap in (4096, 5):
+        a = csp.sample_batch(plan.times, plan.coeffs, sd, cap)
+        o = csp.sample_batch(plan.times, plan.coeffs, sd, cap, one_lane=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], o[1]), (order, S, cap)
+        assert torch.equal(a[0], o[0]), (order, S, cap)
+        assert torch.equal(a[2], o[2]), (order, S, cap)
+    assert int(a[1].min()) >= 2

@@ -33,9 +33,13 @@ for order, pw, vw in ((3, 0.0, 0.0), (4, 0.0, 0.02), (3, 0.5, 0.0), (4, 0.3, 0.0
     cap = 256
     bufs = csp.sample_batch(plan.times, plan.coeffs, 0.7, cap)
     us_samp, (samples, counts, stats) = timed(lambda: csp.sample_batch(plan.times, plan.coeffs, 0.7, cap, out=bufs))
+    bufs1 = csp.sample_batch(plan.times, plan.coeffs, 0.7, cap, one_lane=True)
+    us_one, _ = timed(lambda: csp.sample_batch(plan.times, plan.coeffs, 0.7, cap, out=bufs1, one_lane=True))
+    assert all(torch.equal(x, y) for x, y in zip(bufs, bufs1))
     n_s = counts.double().mean().item()
     print(json.dumps({"order": order, "path_weight": pw, "B": B, "S": S,
                       "plan_us": round(us_plan, 1), "plans_per_s": round(B / us_plan * 1e6),
                       "mean_resolve_iterations": round(plan.iterations.double().mean().item(), 3),
                       "sample_us": round(us_samp, 1), "trajectories_sampled_per_s": round(B / us_samp * 1e6),
+                      "sample_us_one_lane_kernel": round(us_one, 1),
                       "mean_samples_kept": round(n_s, 1), "max_samples_kept": int(counts.max().item())}), flush=True)
