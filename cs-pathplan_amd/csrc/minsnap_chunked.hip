@@ -315,7 +315,7 @@ minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
                 const int i = isleft ? t + 1 : nch - 1 - (t - j);
                 const int slotD = base + i, slotE = base + (isleft ? i : i - 1);
                 const int sr = isleft ? N : 1, sc = isleft ? 1 : N;   // F = E_i (left) or E_{i-1}^T (right)
-                double Sm[N][N], R[N][N + 3], F[N][N];
+                double Sm[N][N], rc[N][3], Wf[N][N], F[N][N];
                 int e = 0;
 #pragma unroll
                 for (int r = 0; r < N; ++r)
@@ -324,26 +324,27 @@ minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
 #pragma unroll
                 for (int r = 0; r < N; ++r)
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) R[r][N + ax] = lds[(e++) * 64 + slotD] + cr[r][ax];
+                    for (int ax = 0; ax < 3; ++ax) rc[r][ax] = lds[(e++) * 64 + slotD] + cr[r][ax];
 #pragma unroll
                 for (int r = 0; r < N; ++r)
 #pragma unroll
-                    for (int qq = 0; qq < N; ++qq) { F[r][qq] = lds[(IL::OFF_E + r * sr + qq * sc) * 64 + slotE]; R[r][qq] = F[r][qq]; }
-                spd &= SmallSpd<N, N + 3>::solve(Sm, R);   // R = S^-1 [F | rhs]
+                    for (int qq = 0; qq < N; ++qq) { F[r][qq] = lds[(IL::OFF_E + r * sr + qq * sc) * 64 + slotE]; Wf[r][qq] = F[r][qq]; }
+                spd &= SmallSpd<N, N>::solve(Sm, Wf);   // Wf = S^-1 F
+                // carry onto the next interface: -F^T S^-1 F and -F^T S^-1 rc = -(S^-1 F)^T rc (S symmetric)
 #pragma unroll
                 for (int r = 0; r < N; ++r) {
 #pragma unroll
                     for (int qq = 0; qq <= r; ++qq) {
                         double v = 0.0;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], R[k][qq], v);
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], Wf[k][qq], v);
                         cS[r][qq] = v;
                     }
 #pragma unroll
                     for (int ax = 0; ax < 3; ++ax) {
                         double v = 0.0;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) v = __builtin_fma(-F[k][r], R[k][N + ax], v);
+                        for (int k = 0; k < N; ++k) v = __builtin_fma(-Wf[k][r], rc[k][ax], v);
                         cr[r][ax] = v;
                     }
                 }
