@@ -37,7 +37,7 @@ FLAG_F32_ARITH = 0x8
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
-    "csp_minsnap_solve_batch", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
+    "csp_minsnap_solve_batch", "csp_minsnap_solve_batch_sharded", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
@@ -75,6 +75,8 @@ if not os.path.exists(LIB_PATH):
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.csp_minsnap_solve_batch.restype = ctypes.c_int
 _lib.csp_minsnap_solve_batch.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
+_lib.csp_minsnap_solve_batch_sharded.restype = ctypes.c_int
+_lib.csp_minsnap_solve_batch_sharded.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
 _lib.csp_minsnap_workspace_bytes.restype = ctypes.c_size_t
 _lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_time_alloc_batch.restype = ctypes.c_int
@@ -170,7 +172,7 @@ class Result:
 
 def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
                 seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
-                want_max_dev=False, want_status=False, out=None, workspace=None, stream=None,
+                want_max_dev=False, want_status=False, out=None, workspace=None, stream=None, ngpu=None,
                 force_generic=False, segment_major=False, no_persistent=False, f32_arith=False):
     """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
 
@@ -265,10 +267,15 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_HOST, per,
                      seg_offsets.ctypes.data if ragged else None, max_segments or 0,
                      vwp.ctypes.data if vwp is not None else None, -1, flags)
-    rc = _lib.csp_minsnap_solve_batch(
-        ctypes.byref(desc), waypoints.ctypes.data, times.ctypes.data, bc.ctypes.data, out.ctypes.data,
-        md.ctypes.data if md is not None else None, stt.ctypes.data if stt is not None else None,
-        None, 0, None)
+    if ngpu is not None:   # one process, the batch cut into contiguous chunks over `ngpu` devices (host arrays only)
+        rc = _lib.csp_minsnap_solve_batch_sharded(
+            ctypes.byref(desc), waypoints.ctypes.data, times.ctypes.data, bc.ctypes.data, out.ctypes.data,
+            md.ctypes.data if md is not None else None, stt.ctypes.data if stt is not None else None, int(ngpu))
+    else:
+        rc = _lib.csp_minsnap_solve_batch(
+            ctypes.byref(desc), waypoints.ctypes.data, times.ctypes.data, bc.ctypes.data, out.ctypes.data,
+            md.ctypes.data if md is not None else None, stt.ctypes.data if stt is not None else None,
+            None, 0, None)
     _check(rc)
     return Result(out, md, stt, kernel_name(desc))
 

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -244,6 +245,58 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
     if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, d_md.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
     if (status) CSP_HIP(hipMemcpyAsync(status, d_st.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
     CSP_HIP(hipStreamSynchronize(st));
+    return CSP_OK;
+}
+
+int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
+                                    const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (desc->mem_space != CSP_MEM_HOST || (desc->flags & CSP_FLAG_SEGMENT_MAJOR)) return CSP_ERR_INVALID_ARG;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
+    const int have = csp_minsnap_device_count();
+    if (have <= 0) return CSP_ERR_NO_DEVICE;
+    if (ngpu <= 0) ngpu = have;
+    if (ngpu > have) return CSP_ERR_INVALID_ARG;
+    if ((int64_t)ngpu > s.B) ngpu = (int)s.B;
+    const size_t m = 2 * (size_t)s.order;
+    struct Chunk {
+        csp_minsnap_desc d;
+        std::vector<int64_t> off;   // ragged: the chunk's own prefix sums
+        int rc = CSP_OK;
+        std::string err;
+    };
+    std::vector<Chunk> ch((size_t)ngpu);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g) {
+        const int64_t lo = s.B * g / ngpu, hi = s.B * (g + 1) / ngpu;   // contiguous, balanced
+        const int64_t seg_lo = s.ragged ? desc->seg_offsets[lo] : lo * (int64_t)s.S;
+        Chunk &c = ch[(size_t)g];
+        c.d = *desc;
+        c.d.batch = hi - lo;
+        c.d.device_id = g;
+        if (s.ragged) {
+            c.off.resize((size_t)(hi - lo + 1));
+            for (int64_t b = lo; b <= hi; ++b) c.off[(size_t)(b - lo)] = desc->seg_offsets[b] - seg_lo;
+            c.d.seg_offsets = c.off.data();
+        }
+        if (desc->vel_zero_weight_per_traj) c.d.vel_zero_weight_per_traj = desc->vel_zero_weight_per_traj + lo;
+        const char *wp = (const char *)waypoints + (size_t)(seg_lo + lo) * 3 * s.elt;
+        const char *tm = (const char *)times + (size_t)seg_lo * s.elt;
+        const char *bcp = (const char *)bc + (desc->bc_per_trajectory ? (size_t)lo * 12 * s.elt : 0);
+        char *co = (char *)coeffs + (size_t)seg_lo * 3 * m * s.elt;
+        double *md = max_dev ? max_dev + lo : nullptr;
+        int32_t *stt = status ? status + lo : nullptr;
+        th.emplace_back([&c, wp, tm, bcp, co, md, stt]() {
+            c.rc = csp_minsnap_solve_batch(&c.d, wp, tm, bcp, co, md, stt, nullptr, 0, nullptr);
+            if (c.rc != CSP_OK) c.err = g_last_hip_error;   // the worker's thread-local text
+        });
+    }
+    for (auto &t : th) t.join();
+    for (const Chunk &c : ch)
+        if (c.rc != CSP_OK) { g_last_hip_error = c.err; return c.rc; }
     return CSP_OK;
 }
 

@@ -111,6 +111,16 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
 /* Device scratch bytes the call above needs for `desc` (0 when the fixed-size kernel serves it). */
 size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
 
+/* The same solve spread over `ngpu` devices of this node from ONE process (the reference planner
+ * is a single C++ process).  Trajectories are independent
+ * (minimum_snap.cpp has no cross-trajectory term), so the batch is cut into `ngpu` contiguous chunks
+ * and chunk g runs on device g -- staging, kernel and copy-back of the chunks proceed concurrently,
+ * no collective.  Host memory only (desc->mem_space must be CSP_MEM_HOST; desc->device_id is
+ * ignored); synchronous.  ngpu <= 0 uses every gfx950 device; ngpu greater than the device count is
+ * CSP_ERR_INVALID_ARG.  Results are identical to csp_minsnap_solve_batch on one device. */
+int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
+                                    const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu);
+
 /* Replaces the time-allocation step of TrajectoryGeneratorTool::GenerateTrajectoryMatrix
  * (minimum_snap.cpp:59-72): T_i = max(|p_{i+1}-p_i| / V_avg, min_time_s), or min_time_s when
  * V_avg <= 1e-6.  Same layouts / descriptor as the solve (path/vel weights ignored). */

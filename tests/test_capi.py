@@ -100,6 +100,9 @@ def test_no_cpu_fallback(csp):
     with pytest.raises(csp.CspError) as e:
         csp.time_alloc_batch(wp, 5.0, 0.1)
     assert e.value.code == -5
+    with pytest.raises(csp.CspError) as e:
+        csp.solve_batch(wp, tm, order=4, ngpu=2)     # single-process multi-GPU entry
+    assert e.value.code == -5
 
 
 def test_product_code_never_touches_the_oracle():

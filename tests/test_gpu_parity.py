@@ -433,6 +433,32 @@ def test_long_trajectory_properties_at_scale(csp, order, S, B):
     assert np.array_equal(rp, c[:, :, [2, 0, 1], :])
 
 
+def test_single_process_sharded_entry(csp):
+    """csp_minsnap_solve_batch_sharded (one process, contiguous chunks over ngpu devices): with the
+    devices this box has it must reproduce the single-device call bit for bit -- uniform and ragged
+    batches, per-trajectory boundary conditions and weights -- and reject more devices than exist."""
+    rng = np.random.default_rng(7)
+    n = csp.device_count()
+    wp, tm = synth.make_batch(1000, 16, config_id=3)
+    bc = rng.normal(size=(1000, 4, 3))
+    vw = rng.uniform(0.0, 0.2, size=1000)
+    kw = dict(order=4, vel_zero_weight_per_traj=vw, want_status=True, want_max_dev=True)
+    a = csp.solve_batch(wp, tm, bc, **kw)
+    for g in sorted({1, n, 0}):
+        b = csp.solve_batch(wp, tm, bc, ngpu=g, **kw)
+        assert np.array_equal(a.coeffs, b.coeffs) and np.array_equal(a.status, b.status) and np.array_equal(a.max_dev, b.max_dev)
+    trajs = [t for t in synth.make_ragged(120, smin=1, smax=40) if t[0] == 3]
+    rwp = np.concatenate([t[1] for t in trajs])
+    rtm = np.concatenate([t[2] for t in trajs])
+    off = np.concatenate([[0], np.cumsum([len(t[2]) for t in trajs])]).astype(np.int64)
+    a = csp.solve_batch(rwp, rtm, order=3, seg_offsets=off)
+    b = csp.solve_batch(rwp, rtm, order=3, seg_offsets=off, ngpu=n)
+    assert np.array_equal(a.coeffs, b.coeffs)
+    with pytest.raises(csp.CspError) as e:
+        csp.solve_batch(wp, tm, bc, ngpu=n + 1, **kw)
+    assert e.value.code == -1
+
+
 def test_time_alloc(csp, oracle_mod):
     wp, _ = synth.make_batch(300, 16, config_id=3)
     for (v, mt) in [(5.0, 0.1), (200.0, 1.0), (0.0, 0.7)]:
