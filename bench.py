@@ -33,18 +33,18 @@ from tests import synth  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(order, S, wp, tm, budget_s):
+def cpu_baseline(order, S, wp, tm, budget_s, pw=0.0, vw=0.0):
     """Oracle (dense restatement, kind 'port') on all host cores over a bounded sample."""
     import oracle
     oracle.build()
     threads = oracle.max_threads()
     probe = min(4 * threads, wp.shape[0])
     t0 = time.perf_counter()
-    oracle.solve_batch(order, wp[:probe], tm[:probe], nthreads=threads)
+    oracle.solve_batch(order, wp[:probe], tm[:probe], path_weight=pw, vel_zero_weight=vw, nthreads=threads)
     per = (time.perf_counter() - t0) / probe
     n = int(min(wp.shape[0], max(probe, budget_s / max(per, 1e-9))))
     t0 = time.perf_counter()
-    ref, _ = oracle.solve_batch(order, wp[:n], tm[:n], nthreads=threads)
+    ref, _ = oracle.solve_batch(order, wp[:n], tm[:n], path_weight=pw, vel_zero_weight=vw, nthreads=threads)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "solves/s", "cores": threads, "kind": "port",
             "sample": "%d of the %d trajectories of the timed batch, dense LU restatement "
@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--segments", type=int, default=16)
     ap.add_argument("--order", type=int, default=4)
+    ap.add_argument("--path-weight", type=float, default=0.0, help="side benchmark: path-deviation penalty on (row A7)")
+    ap.add_argument("--vel-zero-weight", type=float, default=0.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
@@ -151,7 +153,8 @@ def main():
     d_wp, d_tm = torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev)
     d_bc = torch.zeros((1, 4, 3), dtype=torch.float64, device=dev)
     # descriptor, buffers and workspace are fixed for the run: a step is exactly one C-ABI call
-    prep = csp.PreparedSolve(d_wp, d_tm, d_bc, order=o, force_generic=args.force_generic,
+    prep = csp.PreparedSolve(d_wp, d_tm, d_bc, order=o, path_weight=args.path_weight, vel_zero_weight=args.vel_zero_weight,
+                             force_generic=args.force_generic,
                              segment_major=args.segment_major, no_persistent=args.no_persistent,
                              stream=torch.cuda.current_stream(dev).cuda_stream)
     out, kernel = prep.out, prep.kernel
@@ -201,7 +204,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3: B=%d trajectories/GPU x %d segments, order %d (degree %d), "
-                                   "3 axes, fp64, zero boundary vel/acc, penalties off" % (B, S, o, 2 * o - 1),
+                                   "3 axes, fp64, zero boundary vel/acc, %s" % (B, S, o, 2 * o - 1,
+                                       "penalties off" if args.path_weight == 0.0 and args.vel_zero_weight == 0.0 else
+                                       "path_weight=%g vel_zero_weight=%g (side benchmark)" % (args.path_weight, args.vel_zero_weight)),
                        "batch_per_gpu": B, "segments": S, "order": o, "kernel": kernel,
                        "coeff_layout": "[S][B][3][2o] (CSP_FLAG_SEGMENT_MAJOR)" if args.segment_major else "[B][S][3][2o]",
                        "sharding": "independent trajectories per rank, no collective"},
@@ -218,14 +223,15 @@ def main():
                 csp.solve_batch(wp, tm, order=o, force_generic=args.force_generic)
             res["host_path_solves_per_s"] = B * reps / (time.perf_counter() - t1)
         if world == 1 and not args.no_cpu_baseline:
-            cb, ref, n = cpu_baseline(o, S, wp, tm, args.cpu_budget)
+            cb, ref, n = cpu_baseline(o, S, wp, tm, args.cpu_budget, args.path_weight, args.vel_zero_weight)
             res["cpu_baseline"] = cb
             chk = min(n, 1024)
             got = out.view(S, B, 3, 2 * o).permute(1, 0, 2, 3)[:chk] if args.segment_major else out[:chk]
             res["parity_max_rel_err"] = synth.rel_err(got.cpu().numpy(), ref[:chk])
             import oracle
             nld = 128  # 80-bit long-double build of the oracle as the yardstick for both
-            ld, _ = oracle.solve_batch(o, wp[:nld], tm[:nld], nthreads=oracle.max_threads(), long_double=True)
+            ld, _ = oracle.solve_batch(o, wp[:nld], tm[:nld], path_weight=args.path_weight, vel_zero_weight=args.vel_zero_weight,
+                                       nthreads=oracle.max_threads(), long_double=True)
             res["parity_vs_long_double"] = {"hip": synth.rel_err(got[:nld].cpu().numpy(), ld),
                                             "cpu_port_fp64": synth.rel_err(ref[:nld], ld), "trajectories": nld}
         print(json.dumps(res), flush=True)
