@@ -6,8 +6,10 @@
 #include "minsnap_launch.h"
 
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -98,6 +100,19 @@ int select_device(int device_id) {
         return CSP_ERR_NO_DEVICE;
     }
     return CSP_OK;
+}
+
+// Smallest double x with sqrt(x) >= d under IEEE rounding (sqrt is monotone), so that the kernels can
+// test the squared distance: d2 >= x  <=>  sqrt(d2) >= d.  d <= 0 keeps everything (x = 0), NaN nothing.
+double keep_threshold(double d) {
+    if (std::isnan(d)) return d;
+    if (d <= 0.0) return 0.0;
+    if (std::isinf(d)) return d;
+    double x = d * d;
+    if (std::isinf(x)) x = std::numeric_limits<double>::max();
+    while (x > 0.0 && std::sqrt(std::nextafter(x, 0.0)) >= d) x = std::nextafter(x, 0.0);
+    while (std::sqrt(x) < d) x = std::nextafter(x, std::numeric_limits<double>::infinity());
+    return x;
 }
 
 struct DevBuf {
@@ -453,6 +468,7 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     hipStream_t st = (hipStream_t)hip_stream;
     csp::SampleArgs a;
     a.B = s.B; a.S = s.S; a.order = s.order; a.capacity = capacity; a.sample_distance = sample_distance;
+    a.keep_dist2 = keep_threshold(sample_distance);
     a.seg_major = (desc->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
     a.Smax = s.Smax;
     a.one_lane = (desc->flags & CSP_FLAG_FORCE_GENERIC) ? 1 : 0;

@@ -73,6 +73,11 @@ struct SampleArgs {
     int Smax;           // longest trajectory (uniform: S)
     int one_lane;       // force the one-lane-per-trajectory kernel (CSP_FLAG_FORCE_GENERIC)
     double sample_distance;
+    // The reference keeps a candidate when sqrt(d2) >= sample_distance (minimum_snap.cpp:142-150).  sqrt is
+    // monotone and correctly rounded, so that is the same as d2 >= keep_dist2 with keep_dist2 = the smallest
+    // double whose (IEEE) square root reaches sample_distance -- found on the host once per call, which
+    // saves ~27 instructions of fp64 sqrt per candidate.
+    double keep_dist2;
 };
 hipError_t launch_sample(const SampleArgs &a, bool f32, hipStream_t st);
 

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
         for (double t = dt; t <= T + 1e-12; t += dt) {  // accumulated like the reference (:140)
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
-            if (sqrt(dx * dx + dy * dy + dz * dz) >= a.sample_distance) {
+            if (dx * dx + dy * dy + dz * dz >= a.keep_dist2) {   // <=> sqrt(.) >= sample_distance, see SampleArgs
                 prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
                 record(cur);
             }
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
     }
     double dt = 0.1;
     if (dt > T / 10.0) dt = T / 10.0;   // at least 10 evaluations per segment (:126)
-    const double sd = a.sample_distance;
+    const double sd2 = a.keep_dist2;   // d2 >= sd2  <=>  sqrt(d2) >= sample_distance (SampleArgs)
 
     // ---- pass 1: which candidates does this segment keep? ----
     int cnt = 0;
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
         for (double t = dt; t <= T + 1e-12; t += dt) {
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
-            if (sqrt(dx * dx + dy * dy + dz * dz) >= sd) {
+            if (dx * dx + dy * dy + dz * dz >= sd2) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { prev[q] = cur[q]; l2[q] = l1[q]; l1[q] = cur[q]; }
                 ++cnt;
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
         for (double t = dt; t <= T + 1e-12; t += dt) {
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
-            if (sqrt(dx * dx + dy * dy + dz * dz) >= sd) {
+            if (dx * dx + dy * dy + dz * dz >= sd2) {
                 prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
                 record(cur);
             }

@@ -216,6 +216,31 @@ def test_large_time_and_length_scales(csp, oracle_mod):
     assert e_gpu <= 10 * e_dense + 1e-12
 
 
+def test_large_scales_long_trajectories(csp, oracle_mod):
+    """The same kilometre / minute regime on the multi-lane kernel (S = 40: chunk Schur complements,
+    interface solve): it must stay as close to the long-double answer as the dense fp64 oracle does."""
+    S = 40
+    wp, tm = synth.make_batch(6, S, config_id=42)
+    wp = wp * 2000.0
+    tm = tm * 120.0
+    r = csp.solve_batch(wp, tm, order=4)
+    assert r.kernel.startswith("chunked_o4_f64"), r.kernel
+    g = csp.solve_batch(wp, tm, order=4, force_generic=True)
+    z = np.zeros((2, 3))
+    e_gpu = e_gen = e_dense = 0.0
+    for b in range(6):
+        ld, _ = oracle_mod.solve(4, wp[b], z, z, tm[b], long_double=True)
+        dn, _ = oracle_mod.solve(4, wp[b], z, z, tm[b])
+        ld = ld.reshape(S, 3, 8)
+        den = np.max(np.abs(ld), axis=(0, 1))
+        e_gpu = max(e_gpu, float(np.max(np.abs(r.coeffs[b] - ld) / den)))
+        e_gen = max(e_gen, float(np.max(np.abs(g.coeffs[b] - ld) / den)))
+        e_dense = max(e_dense, float(np.max(np.abs(dn.reshape(S, 3, 8) - ld) / den)))
+    print("large scales, S=40: chunked-vs-ld %.2e  generic-vs-ld %.2e  dense-fp64-vs-ld %.2e" % (e_gpu, e_gen, e_dense))
+    assert e_gpu < NORTH_STAR_TOL
+    assert e_gpu <= 10 * max(e_dense, e_gen) + 1e-12
+
+
 def test_device_memory_path_matches_host_path(csp):
     import torch
     wp, tm = synth.make_batch(1000, 16, config_id=3)
