@@ -380,6 +380,12 @@ __global__ void __launch_bounds__(128) minsnap_fixed_path_kernel(GenericArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, role = tid >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    if (a.skip) {
+        // re-solve loop: a slice whose trajectories have all converged costs one load (both waves see
+        // the same mask, so both leave)
+        const int sk = lane < rows ? a.skip[b0 + lane] : 1;
+        if (__builtin_amdgcn_ballot_w64(sk == 0) == 0) return;
+    }
     {
         const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
         const int n_wp = rows * L::WP_ROW / 2;

@@ -28,7 +28,7 @@ def timed(fn, n=5):
 
 wp, _ = synth.make_batch(B, S, config_id=21)
 d_wp = torch.from_numpy(wp * 4.0).cuda()
-for order, pw, vw in ((3, 0.0, 0.0), (4, 0.0, 0.02), (3, 0.5, 0.0), (4, 0.3, 0.0)):
+for order, pw, vw in ((3, 0.0, 0.0), (4, 0.0, 0.02), (3, 0.5, 0.0), (4, 0.3, 0.0), (4, 1e-3, 0.01)):
     us_plan, plan = timed(lambda: csp.plan_batch(d_wp, 5.0, 0.1, order=order, path_weight=pw, vel_zero_weight=vw))
     cap = 256
     bufs = csp.sample_batch(plan.times, plan.coeffs, 0.7, cap)
