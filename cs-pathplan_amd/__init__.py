@@ -34,6 +34,7 @@ FLAG_FORCE_GENERIC = 0x1
 FLAG_SEGMENT_MAJOR = 0x2
 FLAG_NO_PERSISTENT = 0x4
 FLAG_F32_ARITH = 0x8
+FLAG_LONG_SEGMENTS = 0x10
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
@@ -428,11 +429,13 @@ def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, 
     return r
 
 
-def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None, one_lane=False):
+def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None, one_lane=False, long_segments=False):
     """Batched sampling half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:97-205).
     times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2]).
     `out` (device path): a (samples, counts, stats) triple to reuse; rows beyond counts[b] are then
-    left as they were instead of zero.  `one_lane` forces the one-lane-per-trajectory kernel (A/B tests)."""
+    left as they were instead of zero.  `one_lane` forces the one-lane-per-trajectory kernel (A/B tests);
+    `long_segments` (device path) selects the wave-per-trajectory kernel for legs of hundreds of candidates
+    (the host path decides from the times)."""
     on_device = _is_torch(times)
     B, S = times.shape
     order = int(order) if order is not None else int(coeffs.shape[-1]) // 2
@@ -448,7 +451,7 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None,
             counts = torch.empty(B, dtype=torch.int32, device=dev)
             stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
         desc = make_desc(order, B, S, dtype, mem_space=MEM_DEVICE, device_id=dev.index if dev.index is not None else -1,
-                         flags=FLAG_FORCE_GENERIC if one_lane else 0)
+                         flags=(FLAG_FORCE_GENERIC if one_lane else 0) | (FLAG_LONG_SEGMENTS if long_segments else 0))
         st = torch.cuda.current_stream(dev).cuda_stream
         _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.data_ptr(), coeffs.data_ptr(), float(sample_distance),
                                              int(capacity), samples.data_ptr(), counts.data_ptr(), stats.data_ptr(),
@@ -462,7 +465,7 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None,
     samples = np.zeros((B, capacity, 3), dtype=npdt)
     counts = np.empty(B, dtype=np.int32)
     stats = np.empty((B, 2), dtype=np.float64)
-    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST, flags=FLAG_FORCE_GENERIC if one_lane else 0)
+    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST, flags=(FLAG_FORCE_GENERIC if one_lane else 0) | (FLAG_LONG_SEGMENTS if long_segments else 0))
     _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.ctypes.data, coeffs.ctypes.data, float(sample_distance),
                                          int(capacity), samples.ctypes.data, counts.ctypes.data, stats.ctypes.data, None))
     return samples, counts, stats

@@ -472,6 +472,7 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     a.seg_major = (desc->flags & CSP_FLAG_SEGMENT_MAJOR) ? 1 : 0;
     a.Smax = s.Smax;
     a.one_lane = (desc->flags & CSP_FLAG_FORCE_GENERIC) ? 1 : 0;
+    a.long_segments = (desc->flags & CSP_FLAG_LONG_SEGMENTS) ? 1 : 0;
     if (desc->mem_space == CSP_MEM_DEVICE) {
         a.times = times; a.coeffs = coeffs; a.seg_off = s.ragged ? desc->seg_offsets : nullptr;
         a.samples = samples; a.counts = counts; a.stats = stats;
@@ -479,6 +480,16 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
         return e == hipSuccess ? CSP_OK : hip_fail(e, "sample launch");
     }
     const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    if (!a.long_segments && total_seg > 0) {
+        // host-resident times: count the candidates (dt = min(0.1, T/10), :126) and hand long legs --
+        // more than 128 evaluations per segment on average -- to the wave-cooperative sampler
+        double cand = 0.0;
+        for (int64_t i = 0; i < total_seg; ++i) {
+            const double T = s.f32 ? (double)((const float *)times)[i] : ((const double *)times)[i];
+            cand += (T > 1.0 && T < 1e12) ? T * 10.0 : 10.0;
+        }
+        a.long_segments = cand > 128.0 * (double)total_seg;
+    }
     const size_t m = 2 * (size_t)s.order;
     const size_t n_tm = (size_t)total_seg * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
     const size_t n_sm = (size_t)s.B * (size_t)capacity * 3 * s.elt;

@@ -72,6 +72,8 @@ struct SampleArgs {
     int S, order, seg_major;
     int Smax;           // longest trajectory (uniform: S)
     int one_lane;       // force the one-lane-per-trajectory kernel (CSP_FLAG_FORCE_GENERIC)
+    int long_segments;  // hundreds of candidates per segment: one wave per trajectory (CSP_FLAG_LONG_SEGMENTS,
+                        // or found from host-resident times)
     double sample_distance;
     // The reference keeps a candidate when sqrt(d2) >= sample_distance (minimum_snap.cpp:142-150).  sqrt is
     // monotone and correctly rounded, so that is the same as d2 >= keep_dist2 with keep_dist2 = the smallest

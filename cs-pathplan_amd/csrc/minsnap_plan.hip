@@ -52,6 +52,11 @@ hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *ite
     return hipGetLastError();
 }
 
+// Upper bound of the candidate loop `t <= T + 1e-12` (:140).  A non-finite or absurd segment time
+// (> 1e7 s) gets no candidates instead of a loop that never ends on the device (the reference would
+// spin forever on T = inf); such a trajectory is already flagged by the solve's status.
+__device__ __forceinline__ double t_end(double T) { return T <= 1.0e7 ? T + 1e-12 : -1.0; }
+
 template <int M>
 __device__ __forceinline__ void eval_poly(const double (&c)[3][M], double t, double (&out)[3]) {
     // sum of c_k * t^(M-1-k), k ascending, like the reference's eval lambda (:104-117)
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
         if (dt > T / 10.0) dt = T / 10.0;  // at least 10 evaluations per segment (:126)
         eval_poly<M>(c, 0.0, prev);
         if (n == 0) record(prev);
-        for (double t = dt; t <= T + 1e-12; t += dt) {  // accumulated like the reference (:140)
+        for (double t = dt; t <= t_end(T); t += dt) {  // accumulated like the reference (:140)
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
             if (dx * dx + dy * dy + dz * dz >= a.keep_dist2) {   // <=> sqrt(.) >= sample_distance, see SampleArgs
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
         double prev[3], cur[3];
         eval_poly<M>(c, 0.0, prev);
         if (j == 0) { cnt = 1; l1[0] = prev[0]; l1[1] = prev[1]; l1[2] = prev[2]; }   // the very first sample (n == 0)
-        for (double t = dt; t <= T + 1e-12; t += dt) {
+        for (double t = dt; t <= t_end(T); t += dt) {
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
             if (dx * dx + dy * dy + dz * dz >= sd2) {
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
         double prev[3], cur[3];
         eval_poly<M>(c, 0.0, prev);
         if (j == 0) record(prev);
-        for (double t = dt; t <= T + 1e-12; t += dt) {
+        for (double t = dt; t <= t_end(T); t += dt) {
             eval_poly<M>(c, t < T ? t : T, cur);
             const double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
             if (dx * dx + dy * dy + dz * dz >= sd2) {
@@ -369,7 +374,141 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
     if (lane == 0) { stats[b * 2] = max_climb; stats[b * 2 + 1] = min_r; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative sampler for LONG segments (hundreds to thousands of candidates each: kilometre
+// legs sampled every 0.1 s, the reference's own use -- one flight per call).  One wave per
+// trajectory, segments in order, 64 candidates per round:
+//   * candidate times are the reference's running sum (`t += dt`, :140), not k*dt -- after thousands
+//     of additions the two differ by more than the loop's 1e-12 slack -- so a window's 64 times come
+//     from 64 sequential additions captured lane by lane;
+//   * all 64 candidates are evaluated at once; the thinning inside the window is a search: with
+//     `prev` fixed, the next recorded sample is the FIRST later candidate at distance >=
+//     sample_distance (ballot + count-trailing-zeros), `prev` moves there, the lanes behind it
+//     re-test against the new `prev`, and so on -- one short step per recorded sample, none per
+//     dropped candidate;
+//   * the climb-rate / turn-radius statistics (:167-193) need (sample i-2, i-1, i) only: recorded
+//     samples queue up in an LDS ring and every 64 of them are processed by the 64 lanes at once.
+// Same power sums, squared-distance test and statistics formulas as the other two samplers:
+// identical samples, counts and statistics.
+template <int O, typename IO>
+__global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
+    constexpr int M = 2 * O;
+    __shared__ double ring[66 * 3];   // [0],[1]: the two samples before the queued batch; [2..65]: the batch
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    int64_t seg0;
+    int S;
+    if (a.seg_off) { seg0 = a.seg_off[b]; S = (int)(a.seg_off[b + 1] - seg0); }
+    else { seg0 = b * (int64_t)a.S; S = a.S; }
+    IO *out = (IO *)a.samples + b * a.capacity * 3;
+    SampleStats st;          // per-lane partial max / min; p0, p1, n are filled per sample in flush()
+    st.max_climb = 0.0;
+    st.min_r = 1.0e12;
+    int64_t n = 0;           // samples recorded so far (wave-uniform)
+    int nb = 0;              // of which queued in the ring
+    double last[3] = {0, 0, 0};   // the most recently recorded sample (wave-uniform)
+    auto flush = [&]() {
+        __syncthreads();
+        if (lane < nb) {
+            double p[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { p[q] = ring[(2 + lane) * 3 + q]; st.p1[q] = ring[(1 + lane) * 3 + q]; st.p0[q] = ring[lane * 3 + q]; }
+            st.n = n - nb + lane;
+            st.look(p);
+        }
+        __syncthreads();
+        if (lane < 6) ring[lane] = ring[nb * 3 + lane];   // the last two become the predecessors of the next batch
+        nb = 0;
+        __syncthreads();
+    };
+    auto record = [&](const double (&p)[3]) {   // wave-uniform argument
+        if (lane < 3) {
+            if (n < a.capacity) out[n * 3 + lane] = (IO)p[lane == 0 ? 0 : lane == 1 ? 1 : 2];
+            ring[(2 + nb) * 3 + lane] = p[lane == 0 ? 0 : lane == 1 ? 1 : 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) last[q] = p[q];
+        ++n;
+        ++nb;
+        if (nb == 64) flush();
+    };
+    auto bcast = [](double v, int src) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    const double sd2 = a.keep_dist2;
+    for (int seg = 0; seg < S; ++seg) {
+        const IO *rec = (a.seg_major && !a.seg_off) ? (const IO *)a.coeffs + ((int64_t)seg * a.B + b) * 3 * M
+                                                     : (const IO *)a.coeffs + (seg0 + seg) * 3 * M;
+        double c[3][M];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int k = 0; k < M; ++k) c[ax][k] = (double)rec[ax * M + k];
+        const double T = (double)((const IO *)a.times)[seg0 + seg];
+        double dt = 0.1;
+        if (dt > T / 10.0) dt = T / 10.0;
+        double prev[3];
+        eval_poly<M>(c, 0.0, prev);
+        if (n == 0) record(prev);
+        double tb = dt;   // accumulated time of the window's first candidate
+        while (tb <= t_end(T)) {
+            // the window's 64 candidate times: 64 sequential additions, lane i keeps the i-th partial sum
+            double t = tb, run = tb;
+            for (int i = 0; i < 64; ++i) {
+                if (lane == i) t = run;
+                run += dt;
+            }
+            const bool exists = t <= t_end(T);
+            double cur[3];
+            eval_poly<M>(c, t < T ? t : T, cur);
+            double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+            unsigned long long keep = __builtin_amdgcn_ballot_w64(exists && (dx * dx + dy * dy + dz * dz >= sd2));
+            while (keep != 0) {
+                const int first = __builtin_ctzll(keep);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) prev[q] = bcast(cur[q], first);
+                record(prev);
+                // the candidates behind it are now measured from the new reference point
+                dx = cur[0] - prev[0]; dy = cur[1] - prev[1]; dz = cur[2] - prev[2];
+                keep = __builtin_amdgcn_ballot_w64(exists && lane > first && (dx * dx + dy * dy + dz * dz >= sd2));
+            }
+            tb = run;   // = the accumulated time of candidate 64 of this window
+        }
+        if (seg == S - 1) {  // end-point rule (:157-160)
+            double cur[3];
+            eval_poly<M>(c, T, cur);
+            const double ex = last[0] - cur[0], ey = last[1] - cur[1], ez = last[2] - cur[2];
+            if (n == 0 || sqrt(ex * ex + ey * ey + ez * ez) > 1e-6) record(cur);
+        }
+    }
+    flush();
+    double max_climb = st.max_climb, min_r = st.min_r;
+    for (int d = 1; d < 64; d <<= 1) {
+        const double oc = __shfl_xor(max_climb, d, 64), orr = __shfl_xor(min_r, d, 64);
+        max_climb = oc > max_climb ? oc : max_climb;
+        min_r = orr < min_r ? orr : min_r;
+    }
+    if (lane == 0) {
+        a.counts[b] = (int32_t)n;
+        if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+    }
+}
+
 template <typename IO> static hipError_t launch_sample_t(const SampleArgs &a, hipStream_t st) {
+    if (a.long_segments && !a.one_lane) {   // one wave per trajectory, 64 candidates per round
+        const dim3 grid((unsigned)a.B), block(64);
+        switch (a.order) {
+            case 1: hipLaunchKernelGGL((sample_wave_kernel<1, IO>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((sample_wave_kernel<2, IO>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((sample_wave_kernel<3, IO>), grid, block, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((sample_wave_kernel<4, IO>), grid, block, 0, st, a); break;
+            case 5: hipLaunchKernelGGL((sample_wave_kernel<5, IO>), grid, block, 0, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.Smax >= 1 && a.Smax <= 64 && !a.one_lane) {   // one lane per (trajectory, segment)
         int l = 0;
         while ((1 << l) < a.Smax) ++l;

@@ -67,6 +67,9 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 #define CSP_FLAG_F32_ARITH 0x8u      /* CSP_DTYPE_F32 only: compute in fp32 too.  By default fp32 is
                                        the STORAGE type and the arithmetic is fp64 (pure fp32 loses
                                        3..5 digits at order 4..5) */
+#define CSP_FLAG_LONG_SEGMENTS 0x10u /* csp_minsnap_sample_batch with device memory: segments hold hundreds of
+                                       0.1-s candidates each (long legs): sample with one wave per trajectory.
+                                       Host-memory calls decide this themselves from the times. */
 #define CSP_FLAG_NO_PERSISTENT 0x4u  /* fixed kernel: one workgroup per 64 trajectories instead of
                                        persistent workgroups with LDS-DMA prefetch (A/B testing) */
 

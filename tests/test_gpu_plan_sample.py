@@ -124,3 +124,36 @@ def test_resolve_loop_with_converged_slices(csp, oracle_mod):
         assert abs(vwo[b] - info["vel_zero_weight"]) <= 1e-15
         assert abs(md[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
         assert np.max(np.abs(co[b] - info["coeff"])) < 1e-7 * np.max(np.abs(info["coeff"])), b
+
+
+@pytest.mark.parametrize("order,scale,v_avg,sd", [(4, 3000.0, 30.0, 30.0), (3, 800.0, 12.0, 5.0), (2, 5000.0, 200.0, 300.0)])
+def test_wave_cooperative_sampler_for_long_legs(csp, oracle_mod, order, scale, v_avg, sd):
+    """Kilometre legs at 0.1-s candidates (hundreds to thousands per segment, the reference's own use):
+    one wave per trajectory searches 64 candidates per round.  Must be bitwise the sequential sampler
+    (same accumulated candidate times), on the device path (flag) and on the host path (chosen from
+    the times), and agree with the oracle."""
+    import torch
+    B, S = 7, 5
+    wp, _ = synth.make_batch(B, S, config_id=26)
+    wp = wp * scale
+    plan = csp.plan_batch(torch.from_numpy(wp).cuda(), v_avg, 1.0, order=order)
+    cap = 1 << 15
+    a = csp.sample_batch(plan.times, plan.coeffs, sd, cap, long_segments=True)
+    o = csp.sample_batch(plan.times, plan.coeffs, sd, cap, one_lane=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], o[1]) and torch.equal(a[0], o[0]) and torch.equal(a[2], o[2])
+    assert float(plan.times.max()) / 0.1 > 300          # really long segments
+    h = csp.sample_batch(plan.times.cpu().numpy(), plan.coeffs.cpu().numpy(), sd, cap)   # host path picks the wave kernel
+    assert np.array_equal(h[1], a[1].cpu().numpy()) and np.array_equal(h[0], a[0].cpu().numpy())
+    for b in (0, B - 1):
+        ref, info = oracle_mod.generate_trajectory(wp[b], order=order, v_avg=v_avg, min_time_s=1.0, sample_distance=sd)
+        n = int(a[1][b])
+        assert n == len(ref), (b, n, len(ref))
+        assert np.max(np.abs(a[0][b, :n].cpu().numpy() - ref)) < 1e-7 * np.max(np.abs(ref))
+    # a non-finite segment time must not hang the device: that trajectory simply gets no candidates
+    tm = plan.times.clone()
+    tm[3, 2] = float("inf")
+    for kw in (dict(long_segments=True), dict(), dict(one_lane=True)):
+        r = csp.sample_batch(tm, plan.coeffs, sd, cap, **kw)
+        torch.cuda.synchronize()
+        assert int(r[1][3]) >= 1
