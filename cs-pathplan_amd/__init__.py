@@ -429,15 +429,23 @@ def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, 
     return r
 
 
-def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None, one_lane=False, long_segments=False):
+def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None, one_lane=False, long_segments=False,
+                 seg_offsets=None):
     """Batched sampling half of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:97-205).
     times [B,S], coeffs [B,S,3,2o].  Returns (samples [B,capacity,3], counts [B], stats [B,2]).
     `out` (device path): a (samples, counts, stats) triple to reuse; rows beyond counts[b] are then
     left as they were instead of zero.  `one_lane` forces the one-lane-per-trajectory kernel (A/B tests);
     `long_segments` (device path) selects the wave-per-trajectory kernel for legs of hundreds of candidates
-    (the host path decides from the times)."""
+    (the host path decides from the times).  Ragged batches (host arrays): times [sum S_b], coeffs [sum S_b,3,2o],
+    `seg_offsets` [B+1]."""
     on_device = _is_torch(times)
-    B, S = times.shape
+    if seg_offsets is not None:
+        if on_device:
+            raise ValueError("ragged sampling takes host arrays here")
+        seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.int64)
+        B, S = seg_offsets.shape[0] - 1, 0
+    else:
+        B, S = times.shape
     order = int(order) if order is not None else int(coeffs.shape[-1]) // 2
     if on_device:
         import torch
@@ -465,7 +473,10 @@ def sample_batch(times, coeffs, sample_distance, capacity, order=None, out=None,
     samples = np.zeros((B, capacity, 3), dtype=npdt)
     counts = np.empty(B, dtype=np.int32)
     stats = np.empty((B, 2), dtype=np.float64)
-    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST, flags=(FLAG_FORCE_GENERIC if one_lane else 0) | (FLAG_LONG_SEGMENTS if long_segments else 0))
+    desc = make_desc(order, B, S, dtype, mem_space=MEM_HOST,
+                     seg_offsets_ptr=seg_offsets.ctypes.data if seg_offsets is not None else None,
+                     max_segments=int(np.max(np.diff(seg_offsets))) if seg_offsets is not None and B else 0,
+                     flags=(FLAG_FORCE_GENERIC if one_lane else 0) | (FLAG_LONG_SEGMENTS if long_segments else 0))
     _check(_lib.csp_minsnap_sample_batch(ctypes.byref(desc), times.ctypes.data, coeffs.ctypes.data, float(sample_distance),
                                          int(capacity), samples.ctypes.data, counts.ctypes.data, stats.ctypes.data, None))
     return samples, counts, stats

@@ -157,3 +157,25 @@ def test_wave_cooperative_sampler_for_long_legs(csp, oracle_mod, order, scale, v
         r = csp.sample_batch(tm, plan.coeffs, sd, cap, **kw)
         torch.cuda.synchronize()
         assert int(r[1][3]) >= 1
+
+
+def test_ragged_sampling_equals_per_trajectory_sampling(csp):
+    """Ragged batches (seg_offsets) through all three samplers: trajectory b of the ragged call must be
+    bitwise the uniform single-trajectory call."""
+    rng = np.random.default_rng(9)
+    order, sd, cap = 3, 0.6, 2048
+    lens = [1, 5, 64, 2, 17, 33, 8]
+    tms, cos = [], []
+    for S in lens:
+        wp, _ = synth.make_batch(1, S, config_id=27)
+        plan = csp.plan_batch(wp * 3.0, 5.0, 0.1, order=order)
+        tms.append(plan.times[0]); cos.append(plan.coeffs[0])
+    tm, co = np.concatenate(tms), np.concatenate(cos)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for kw in (dict(), dict(one_lane=True), dict(long_segments=True)):
+        smp, cnt, stats = csp.sample_batch(tm, co, sd, cap, order=order, seg_offsets=off, **kw)
+        for b, S in enumerate(lens):
+            s1, c1, st1 = csp.sample_batch(tms[b][None], cos[b][None], sd, cap, one_lane=True)
+            assert cnt[b] == c1[0], (kw, b)
+            assert np.array_equal(smp[b, :cnt[b]], s1[0, :c1[0]]), (kw, b)
+            assert np.array_equal(stats[b], st1[0]), (kw, b)
