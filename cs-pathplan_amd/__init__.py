@@ -35,6 +35,7 @@ FLAG_SEGMENT_MAJOR = 0x2
 FLAG_NO_PERSISTENT = 0x4
 FLAG_F32_ARITH = 0x8
 FLAG_LONG_SEGMENTS = 0x10
+FLAG_SPAN = 0x20
 TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
@@ -174,7 +175,7 @@ class Result:
 def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0,
                 seg_offsets=None, max_segments=None, vel_zero_weight_per_traj=None,
                 want_max_dev=False, want_status=False, out=None, workspace=None, stream=None, ngpu=None,
-                force_generic=False, segment_major=False, no_persistent=False, f32_arith=False):
+                force_generic=False, segment_major=False, no_persistent=False, f32_arith=False, span=False):
     """Batched SolveQPClosedForm (math_util/minimum_snap.hpp:45-53).
 
     numpy inputs  -> CSP_MEM_HOST (staged through the device, synchronous);
@@ -188,7 +189,8 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
     on_device = _is_torch(waypoints)
     ragged = seg_offsets is not None
     flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
-             | (FLAG_NO_PERSISTENT if no_persistent else 0) | (FLAG_F32_ARITH if f32_arith else 0))
+             | (FLAG_NO_PERSISTENT if no_persistent else 0) | (FLAG_F32_ARITH if f32_arith else 0)
+             | (FLAG_SPAN if span else 0))
     if segment_major and ragged:
         raise ValueError("segment_major needs a uniform batch")
     m = 2 * int(order)
@@ -288,7 +290,7 @@ class PreparedSolve:
 
     def __init__(self, waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_weight=0.0, out=None,
                  force_generic=False, segment_major=False, no_persistent=False, stream=None,
-                 seg_offsets=None, max_segments=None):
+                 seg_offsets=None, max_segments=None, span=False):
         import torch
         if not (_is_torch(waypoints) and waypoints.is_cuda):
             raise ValueError("PreparedSolve takes CUDA tensors (device memory space)")
@@ -312,7 +314,7 @@ class PreparedSolve:
         shape = (total, 3, m) if ragged else ((S, B, 3, m) if segment_major else (B, S, 3, m))
         self.out = out if out is not None else torch.empty(shape, dtype=tdt, device=self.dev)
         flags = ((FLAG_FORCE_GENERIC if force_generic else 0) | (FLAG_SEGMENT_MAJOR if segment_major else 0)
-                 | (FLAG_NO_PERSISTENT if no_persistent else 0))
+                 | (FLAG_NO_PERSISTENT if no_persistent else 0) | (FLAG_SPAN if span else 0))
         self.desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, self.bc.shape[0] == B and B != 1,
                               seg_offsets_ptr=self.off.data_ptr() if ragged else None, max_segments=(max_segments or 0) if ragged else 0,
                               device_id=self.dev.index if self.dev.index is not None else -1, flags=flags)

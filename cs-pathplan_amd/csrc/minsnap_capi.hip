@@ -68,16 +68,26 @@ bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
     return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged, (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }
 
-// the multi-lane workspace-free kernel takes what the fixed buckets do not: ragged batches, S > 16,
-// fp32 storage (minsnap_chunked.hip)
-bool use_chunked(const csp_minsnap_desc *d, const Shape &s) {
+// very long trajectories (256 < S <= 1024; from 17 segments with CSP_FLAG_SPAN): spans of 16 segments per
+// lane (minsnap_span.hip).  Below 257 segments the chunked kernel is faster: the span kernel re-reads its
+// inputs once per elimination step and 2048 resident waves x 34 KB do not stay in L2.
+bool use_span(const csp_minsnap_desc *d, const Shape &s) {
     if ((d->flags & CSP_FLAG_FORCE_GENERIC) || use_fixed(d, s)) return false;
+    if (s.Smax <= 256 && !(d->flags & CSP_FLAG_SPAN)) return false;
+    return csp::span_supported(s.order, s.Smax, s.f32 && (d->flags & CSP_FLAG_F32_ARITH), d->path_weight,
+                               (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
+}
+
+// the multi-lane workspace-free kernel takes what the fixed buckets and the span kernel do not: short
+// ragged batches, fp32 storage at S <= 16 (minsnap_chunked.hip)
+bool use_chunked(const csp_minsnap_desc *d, const Shape &s) {
+    if ((d->flags & CSP_FLAG_FORCE_GENERIC) || use_fixed(d, s) || use_span(d, s)) return false;
     return csp::chunked_supported(s.order, s.Smax, s.f32 && (d->flags & CSP_FLAG_F32_ARITH), d->path_weight,
                                   (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }
 
 size_t ws_bytes(const csp_minsnap_desc *d, const Shape &s, size_t *tstar_off) {
-    if (use_fixed(d, s) || use_chunked(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
+    if (use_fixed(d, s) || use_span(d, s) || use_chunked(d, s)) { if (tstar_off) *tstar_off = 0; return 0; }
     const size_t ws_elt = (s.f32 && (d->flags & CSP_FLAG_F32_ARITH)) ? 4 : 8;  // workspace holds the arithmetic type
     size_t factors = align_up((size_t)(s.Smax > 1 ? s.Smax - 1 : 0) * csp::generic_ws_entries(s.order) *
                                   (size_t)s.B * ws_elt, 256);
@@ -145,8 +155,9 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
     if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;
     // the chunked kernel reads scalars and stores 16-byte pieces (8-byte for fp32 with odd order)
-    if (use_chunked(d, s) && ((uintptr_t)co & ((s.f32 && (s.order & 1)) ? 7u : 15u))) return CSP_ERR_INVALID_ARG;
+    if ((use_chunked(d, s) || use_span(d, s)) && ((uintptr_t)co & ((s.f32 && (s.order & 1)) ? 7u : 15u))) return CSP_ERR_INVALID_ARG;
     hipError_t e = use_fixed(d, s) ? csp::launch_fixed(a, st)
+                 : use_span(d, s)    ? csp::launch_span(a, s.f32, s.Smax, st)
                  : use_chunked(d, s) ? csp::launch_chunked(a, s.f32, s.Smax, st)
                                      : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -194,6 +205,11 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc) {
     Shape s;
     if (validate(desc, s) != CSP_OK) return nullptr;
     if (use_fixed(desc, s)) return csp::fixed_kernel_name(s.order, s.S, desc->path_weight > 0.0);
+    if (use_span(desc, s)) {
+        std::snprintf(name, sizeof name, "span_o%d_%s_l%d%s", s.order, s.f32 ? "f32io_f64" : "f64",
+                      1 << csp::span_lanes_log2(s.Smax), s.ragged ? "_ragged" : "");
+        return name;
+    }
     if (use_chunked(desc, s)) {
         std::snprintf(name, sizeof name, "chunked_o%d_%s_l%d%s", s.order, s.f32 ? "f32io_f64" : "f64",
                       1 << csp::chunked_lanes_log2(s.Smax), s.ragged ? "_ragged" : "");

@@ -48,6 +48,12 @@ bool chunked_supported(int order, int Smax, bool f32_arith, double path_weight, 
 int chunked_lanes_log2(int Smax);
 hipError_t launch_chunked(const GenericArgs &a, bool f32, int Smax, hipStream_t st);
 
+// Long trajectories (16 < S <= 1024): spans of 16 segments per lane, recovery by recomputation
+// (minsnap_span.hip); same options as the chunked kernel.
+bool span_supported(int order, int Smax, bool f32_arith, double path_weight, bool seg_major);
+int span_lanes_log2(int Smax);
+hipError_t launch_span(const GenericArgs &a, bool f32, int Smax, hipStream_t st);
+
 struct TimeAllocArgs {
     const void *wp;
     void *times;

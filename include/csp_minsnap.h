@@ -70,6 +70,8 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 #define CSP_FLAG_LONG_SEGMENTS 0x10u /* csp_minsnap_sample_batch with device memory: segments hold hundreds of
                                        0.1-s candidates each (long legs): sample with one wave per trajectory.
                                        Host-memory calls decide this themselves from the times. */
+#define CSP_FLAG_SPAN 0x20u          /* 16 < S <= 256: use the 16-segments-per-lane kernel (the default beyond 256
+                                       segments) instead of the 4-segments-per-lane one (A/B testing) */
 #define CSP_FLAG_NO_PERSISTENT 0x4u  /* fixed kernel: one workgroup per 64 trajectories instead of
                                        persistent workgroups with LDS-DMA prefetch (A/B testing) */
 

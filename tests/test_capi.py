@@ -63,7 +63,12 @@ def test_validation_and_dispatch_names(csp):
     assert csp.kernel_name(csp.make_desc(4, 100, 64)) == "chunked_o4_f64_l16"
     assert csp.kernel_name(csp.make_desc(4, 100, 256)) == "chunked_o4_f64_l64"
     assert csp.workspace_bytes(csp.make_desc(4, 100, 256)) == 0
-    assert csp.kernel_name(csp.make_desc(4, 100, 257)) == "generic_o4_f64"
+    assert csp.kernel_name(csp.make_desc(4, 100, 257)) == "span_o4_f64_l32"      # very long: lanes x <= 16 segments
+    assert csp.kernel_name(csp.make_desc(4, 100, 1024)) == "span_o4_f64_l64"
+    assert csp.workspace_bytes(csp.make_desc(4, 100, 1024)) == 0
+    assert csp.kernel_name(csp.make_desc(4, 100, 1025)) == "generic_o4_f64"
+    assert csp.kernel_name(csp.make_desc(4, 100, 64, flags=csp.FLAG_SPAN)) == "span_o4_f64_l4"
+    assert csp.kernel_name(csp.make_desc(4, 100, 16, flags=csp.FLAG_SPAN)) == "fixed_o4_s16_f64"
     assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "chunked_o4_f64_l1"
     assert csp.kernel_name(csp.make_desc(1, 100, 5)) == "generic_o1_f64"         # order 1 has no free derivative
     assert csp.kernel_name(csp.make_desc(3, 100, 16, flags=csp.FLAG_SEGMENT_MAJOR)) == "generic_o3_f64"

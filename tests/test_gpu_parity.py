@@ -225,9 +225,13 @@ def test_large_scales_long_trajectories(csp, oracle_mod):
     tm = tm * 120.0
     r = csp.solve_batch(wp, tm, order=4)
     assert r.kernel.startswith("chunked_o4_f64"), r.kernel
+    rc = csp.solve_batch(wp, tm, order=4, span=True)
+    assert rc.kernel.startswith("span_o4_f64"), rc.kernel
     g = csp.solve_batch(wp, tm, order=4, force_generic=True)
     z = np.zeros((2, 3))
     e_gpu = e_gen = e_dense = 0.0
+    e_chk = max(float(np.max(np.abs(rc.coeffs[b] - r.coeffs[b]) / np.max(np.abs(r.coeffs[b]), axis=(0, 1)))) for b in range(6))
+    assert e_chk < 1e-9
     for b in range(6):
         ld, _ = oracle_mod.solve(4, wp[b], z, z, tm[b], long_double=True)
         dn, _ = oracle_mod.solve(4, wp[b], z, z, tm[b])
@@ -273,7 +277,7 @@ def test_f32_storage_mixed_batch_c5(csp, oracle_mod):
     spec.loader.exec_module(mixed)
     trajs = synth.make_ragged(240)
     got, kernels = mixed.solve_mixed(trajs, dtype=np.float32)
-    assert all(k.startswith("chunked_o") and "f32io_f64" in k and k.endswith("_ragged") for k in kernels), kernels
+    assert all(k.startswith(("chunked_o", "span_o")) and "f32io_f64" in k and k.endswith("_ragged") for k in kernels), kernels
     got32, _ = mixed.solve_mixed(trajs, dtype=np.float32, f32_arith=True)
     worst = {3: 0.0, 4: 0.0, 5: 0.0}
     worst32 = {3: 0.0, 4: 0.0, 5: 0.0}
@@ -303,15 +307,21 @@ def test_ragged_batch(csp, oracle_mod):
         assert synth.rel_err(got.reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, i
 
 
+@pytest.mark.parametrize("span", [False, True])
 @pytest.mark.parametrize("order", [2, 3, 4, 5])
-def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order):
-    """The workspace-free multi-lane kernel (ragged batches, S > 16, fp32 storage): whole batches against
+def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order, span):
+    """The workspace-free multi-lane kernels (ragged batches, S > 16, fp32 storage): whole batches against
     the generic kernel, sampled trajectories against the oracle.  Covers every lanes-per-trajectory
-    bucket (S <= 4 .. S <= 256), chunk sizes 1..4, per-trajectory boundary conditions and weights."""
+    bucket, chunk sizes 1..4 (chunked kernel) and span sizes 1..16 (span kernel: beyond 256 segments, or from
+    17 segments with CSP_FLAG_SPAN), per-trajectory boundary conditions and weights."""
     import torch
     rng = np.random.default_rng(200 + order)
     tol_g = 1e-6 if order == 5 else 1e-8
-    for smin, smax, B in ((1, 4, 300), (1, 9, 257), (3, 16, 200), (5, 33, 150), (17, 64, 130), (60, 130, 40), (200, 256, 9)):
+    classes = ((1, 4, 300), (1, 9, 257), (3, 16, 200), (5, 33, 150), (17, 64, 130), (60, 130, 40), (200, 256, 9))
+    if span:
+        classes = classes[3:] + ((1, 40, 333),)
+    classes = classes + ((300, 700, 6),)
+    for smin, smax, B in classes:
         S_b = rng.integers(smin, smax + 1, size=B)
         S_b[0], S_b[-1] = smin, smax
         off = np.concatenate([[0], np.cumsum(S_b)]).astype(np.int64)
@@ -326,8 +336,9 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order):
         d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc, vw)]
         d_off = torch.from_numpy(off).cuda()
         kw = dict(order=order, seg_offsets=d_off, max_segments=int(smax), vel_zero_weight_per_traj=d[3], want_status=True, want_max_dev=True)
-        r = csp.solve_batch(d[0], d[1], d[2], **kw)
-        assert r.kernel.startswith("chunked_o%d_f64_l" % order) and r.kernel.endswith("_ragged"), r.kernel
+        r = csp.solve_batch(d[0], d[1], d[2], span=span, **kw)
+        fam = "span" if (smax > 256 or (smax > 16 and span)) else "chunked"
+        assert r.kernel.startswith("%s_o%d_f64_l" % (fam, order)) and r.kernel.endswith("_ragged"), r.kernel
         g = csp.solve_batch(d[0], d[1], d[2], force_generic=True, **kw)
         torch.cuda.synchronize()
         assert not r.status.cpu().numpy().any(), (order, smax)
@@ -337,8 +348,8 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order):
             e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), gg[off[i]:off[i + 1]].reshape(1, -1))
             assert e < tol_g, (order, smax, i, int(S_b[i]), e)
         for i in sorted({0, B // 2, B - 1}):
-            if S_b[i] > 64 and order == 5:
-                continue   # the dense oracle itself is ill-conditioned there
+            if (S_b[i] > 64 and order == 5) or S_b[i] > 260:
+                continue   # the dense oracle itself is ill-conditioned / too slow there
             ref, _ = oracle_mod.solve(order, wps[i], bc[i, [0, 1]], bc[i, [2, 3]], tms[i], 0.0, float(vw[i]))
             e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), ref.reshape(1, -1))
             assert e < (1e-5 if order == 5 else 1e-7), (order, smax, i, e)
@@ -346,14 +357,16 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order):
     for S in (17, 32, 100):
         wp, tm = synth.make_batch(77, S, config_id=400 + order)
         bc1 = rng.normal(size=(1, 4, 3))
-        r = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, want_status=True)
-        assert r.kernel == "chunked_o%d_f64_l%d" % (order, 8 if S <= 32 else 32), r.kernel
+        r = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, want_status=True, span=span)
+        assert r.kernel == ("chunked_o%d_f64_l%d" % (order, 8 if S <= 32 else 32) if not span else
+                            "span_o%d_f64_l%d" % (order, 2 if S <= 32 else 8)), r.kernel
         g = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, force_generic=True)
         assert not r.status.any()
         assert synth.rel_err(r.coeffs, g.coeffs) < tol_g, (order, S)
-        r32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05)
+        r32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05,
+                              span=span)
         g32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05, force_generic=True)
-        assert r32.kernel.startswith("chunked_o%d_f32io_f64_l" % order), r32.kernel
+        assert r32.kernel.startswith("%s_o%d_f32io_f64_l" % ("span" if span else "chunked", order)), r32.kernel
         assert r32.coeffs.dtype == np.float32
         assert synth.rel_err(r32.coeffs, g32.coeffs) < 1e-6, (order, S)
 
@@ -362,11 +375,12 @@ def test_chunked_kernel_status(csp):
     wp, tm = synth.make_batch(70, 40, config_id=3)
     tm[5, 3] = 0.0
     tm[33, 39] = float("nan")
-    r = csp.solve_batch(wp, tm, order=4, want_status=True)
-    assert r.kernel.startswith("chunked_"), r.kernel
-    assert np.flatnonzero(r.status).tolist() == [5, 33]
-    good = np.setdiff1d(np.arange(70), [5, 33])
-    assert np.isfinite(r.coeffs[good]).all()
+    for span in (False, True):
+        r = csp.solve_batch(wp, tm, order=4, want_status=True, span=span)
+        assert r.kernel.startswith("span_" if span else "chunked_"), r.kernel
+        assert np.flatnonzero(r.status).tolist() == [5, 33]
+        good = np.setdiff1d(np.arange(70), [5, 33])
+        assert np.isfinite(r.coeffs[good]).all()
 
 
 def test_full_size_properties(csp):
@@ -421,8 +435,9 @@ def test_full_size_properties(csp):
     assert np.max(np.abs(r2 - exp)) < 1e-9 * np.max(np.abs(exp))
 
 
+@pytest.mark.parametrize("span", [False, True])
 @pytest.mark.parametrize("order,S,B", [(4, 64, 16384), (3, 37, 20000), (4, 200, 2048)])
-def test_long_trajectory_properties_at_scale(csp, order, S, B):
+def test_long_trajectory_properties_at_scale(csp, order, S, B, span):
     """The chunked kernel on batches of thousands of waves: interpolation, continuity of the 2(o-1)
     derivatives the optimum leaves continuous at interior waypoints (chunk interfaces included),
     boundary conditions, axis permutation -- no oracle involved."""
@@ -430,8 +445,8 @@ def test_long_trajectory_properties_at_scale(csp, order, S, B):
     m = 2 * order
     wp, tm = synth.make_batch(B, S, config_id=11)
     d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
-    r = csp.solve_batch(d_wp, d_tm, order=order, want_status=True)
-    assert r.kernel.startswith("chunked_o%d_f64" % order), r.kernel
+    r = csp.solve_batch(d_wp, d_tm, order=order, want_status=True, span=span)
+    assert r.kernel.startswith("%s_o%d_f64" % ("span" if span else "chunked", order)), r.kernel
     c = r.coeffs.cpu().numpy()
     assert not r.status.cpu().numpy().any()
     T = tm[:, :, None]
@@ -454,7 +469,7 @@ def test_long_trajectory_properties_at_scale(csp, order, S, B):
         assert np.max(np.abs(deriv_at(c[:, 0], np.zeros((B, 3)), j))) < 1e-12
         assert np.max(np.abs(deriv_at(c[:, -1], np.broadcast_to(T[:, -1], (B, 3)), j))) < 1e-7
     perm = torch.from_numpy(np.ascontiguousarray(wp[:, :, [2, 0, 1]])).cuda()
-    rp = csp.solve_batch(perm, d_tm, order=order).coeffs.cpu().numpy()
+    rp = csp.solve_batch(perm, d_tm, order=order, span=span).coeffs.cpu().numpy()
     assert np.array_equal(rp, c[:, :, [2, 0, 1], :])
 
 
