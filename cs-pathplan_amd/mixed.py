@@ -8,8 +8,9 @@ import numpy as np
 
 # The workspace-free ragged kernel gives every trajectory of a call the same number of lanes, chosen
 # from the call's longest trajectory (4 segments per lane): one call per power-of-two length class
-# keeps the lanes of short trajectories busy.
-LENGTH_CLASSES = (4, 8, 16, 32, 64, 128, 256)
+# keeps the lanes of short trajectories busy.  Classes below 16 segments are not split further: at
+# B = 65536 the extra launches cost more than the idle lanes (measured with bench.py --workload c5).
+LENGTH_CLASSES = (16, 32, 64, 128, 256)
 
 
 def length_classes(sorted_lens):
