@@ -133,7 +133,7 @@ struct DevBuf {
 
 int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const void *tm, const void *bc,
              void *co, double *max_dev, int32_t *status, const int64_t *seg_off, const double *vw_per,
-             void *ws, size_t ws_size, hipStream_t st, const int32_t *skip = nullptr) {
+             void *ws, size_t ws_size, hipStream_t st, const int32_t *skip = nullptr, int *tau_buf = nullptr, int tau_mode = 0) {
     size_t tstar_off = 0;
     const size_t need = ws_bytes(d, s, &tstar_off);
     if (need > 0 && (!ws || ws_size < need)) return CSP_ERR_WORKSPACE;
@@ -151,6 +151,8 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.Boffset = 0;
     a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
     a.skip = skip;
+    a.tau_mode = 0;
+    if (tau_buf && use_fixed(d, s)) { a.tstar = tau_buf; a.tau_mode = tau_mode; }   // path kernel inside the re-solve loop
     // the fixed kernel moves 16-byte pieces (LDS-DMA, ds_read_b128, dwordx4 stores)
     const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
     if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;
@@ -371,8 +373,9 @@ size_t csp_minsnap_plan_workspace_bytes(const csp_minsnap_desc *desc) {
     csp_minsnap_desc g = *desc;
     Shape gs;
     validate(&g, gs);
-    // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32
-    return align_up(ws_bytes(&g, gs, nullptr), 256) + align_up((size_t)s.B * 8, 256) * 2 + align_up((size_t)s.B * 4, 256) * 2;
+    // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32 + t* indices [S][B] i32 (path kernel)
+    const size_t tau = (desc->path_weight > 0.0 && use_fixed(&g, gs)) ? align_up((size_t)s.B * (size_t)s.S * 4, 256) : 0;
+    return align_up(ws_bytes(&g, gs, nullptr), 256) + align_up((size_t)s.B * 8, 256) * 2 + align_up((size_t)s.B * 4, 256) * 2 + tau;
 }
 
 int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
@@ -456,12 +459,15 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
     double *vw = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
     double *md = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
     int32_t *iters = (int32_t *)base;                             base += align_up((size_t)s.B * 4, 256);
-    int32_t *done = (int32_t *)base;
+    int32_t *done = (int32_t *)base;                              base += align_up((size_t)s.B * 4, 256);
+    // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
+    int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
     if ((e = csp::launch_resolve_init(vw, iters, done, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
     if (desc->vel_zero_weight_per_traj)
         CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     for (int pass = 0; pass <= 10; ++pass) {  // at most 11 solves (:78-90)
-        rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done);
+        rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done,
+                      tau_buf, pass == 0 ? 1 : 2);
         if (rc != CSP_OK) return rc;
         if ((e = csp::launch_resolve_update(md, vw, iters, done, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_update");
     }

@@ -346,7 +346,23 @@ __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int 
     for (int j = 0; j < HS; ++j) tau[j] = 0;
     bool spd = true;
     double nanacc = 0.0, maxdev = 0.0;
-    path_sweep<O, S, BOTTOM, false, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+    // The pre-solve uses Q_original (no path term, no zero-velocity term, :349), so inside the re-solve
+    // loop -- only vel_zero_weight changes between its passes (:80-90) -- every pass finds the same t*.
+    // tau_mode 2 reads the sample indices a previous pass stored (global order, [segment][trajectory])
+    // instead of repeating the pre-solve and the 17-sample search; tau_mode 1 stores them.
+    if (a.tau_mode == 2) {
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+            const int sg = a.tstar[(int64_t)(BOTTOM ? S - 1 - j : j) * a.B + b];
+            tau[j] = BOTTOM ? 16 - sg : sg;
+        }
+    } else {
+        path_sweep<O, S, BOTTOM, false, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+        if (a.tau_mode == 1 && lane < rows) {
+#pragma unroll
+            for (int j = 0; j < HS; ++j) a.tstar[(int64_t)(BOTTOM ? S - 1 - j : j) * a.B + b] = BOTTOM ? 16 - tau[j] : tau[j];
+        }
+    }
     spd = true;  // the reported status is the penalised solve's
     path_sweep<O, S, BOTTOM, true, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
     // the reference's max_deviation is the maximum over ALL segments and the status covers both

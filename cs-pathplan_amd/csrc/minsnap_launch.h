@@ -31,6 +31,7 @@ struct GenericArgs {
     int64_t Boffset;        // seg_major: first trajectory of this launch inside that batch
     int persistent;         // fixed kernel: persistent workgroups with LDS-DMA prefetch (default on)
     const int32_t *skip;    // generic kernel: [B] non-zero = leave this trajectory untouched (or null)
+    int tau_mode;           // path kernel: 0 find t* each call; 1 find and store in tstar; 2 reuse tstar (re-solve loop)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
