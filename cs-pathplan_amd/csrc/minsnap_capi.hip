@@ -152,7 +152,9 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
     a.persistent = (d->flags & CSP_FLAG_NO_PERSISTENT) ? 0 : 1;
     a.skip = skip;
     a.tau_mode = 0;
-    if (tau_buf && use_fixed(d, s)) { a.tstar = tau_buf; a.tau_mode = tau_mode; }   // path kernel inside the re-solve loop
+    // inside the re-solve loop: the path kernel keeps its t* indices in tau_buf, the generic kernel in its workspace
+    if (use_fixed(d, s)) { if (tau_buf) { a.tstar = tau_buf; a.tau_mode = tau_mode; } }
+    else a.tau_mode = tau_mode;
     // the fixed kernel moves 16-byte pieces (LDS-DMA, ds_read_b128, dwordx4 stores)
     const bool aligned = (((uintptr_t)wp | (uintptr_t)tm | (uintptr_t)co) & 15u) == 0;
     if (use_fixed(d, s) && !aligned) return CSP_ERR_INVALID_ARG;

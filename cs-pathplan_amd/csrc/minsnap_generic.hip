@@ -294,8 +294,10 @@ __global__ void __launch_bounds__(64) minsnap_generic_kernel(GenericArgs a) {
     int status = 0;
     double dev = 0.0;
     if (PATH) {
-        status |= solve_pass<O, IO, R, false>(tv, x0, xS, R(0), R(0), ws, tstar, a.B, b, nullptr);
-        pick_tstar<O, IO, R>(tv, tstar, a.B);
+        if (a.tau_mode != 2) {   // re-solve loop, passes 1..10: the pre-solve ignores vel_zero_weight, t* is unchanged
+            status |= solve_pass<O, IO, R, false>(tv, x0, xS, R(0), R(0), ws, tstar, a.B, b, nullptr);
+            pick_tstar<O, IO, R>(tv, tstar, a.B);
+        }
         status = solve_pass<O, IO, R, true>(tv, x0, xS, pw, vw, ws, tstar, a.B, b, &dev);
     } else {
         status = solve_pass<O, IO, R, false>(tv, x0, xS, R(0), vw, ws, tstar, a.B, b, a.max_dev ? &dev : nullptr);

@@ -179,3 +179,22 @@ def test_ragged_sampling_equals_per_trajectory_sampling(csp):
             assert cnt[b] == c1[0], (kw, b)
             assert np.array_equal(smp[b, :cnt[b]], s1[0, :c1[0]]), (kw, b)
             assert np.array_equal(stats[b], st1[0]), (kw, b)
+
+
+def test_resolve_loop_on_the_generic_kernel(csp, oracle_mod):
+    """More than 16 segments with the path penalty: the re-solve loop runs on the generic kernel, whose
+    passes after the first also reuse the stored t* indices.  Iteration counts, weights, deviation and
+    coefficients against the oracle."""
+    B, S, order = 10, 20, 3
+    wp, _ = synth.make_batch(B, S, config_id=28)
+    wp = wp * 4.0
+    plan = csp.plan_batch(wp, 5.0, 0.1, order=order, path_weight=0.5, vel_zero_weight=0.0)
+    assert not plan.status.any()
+    assert plan.iterations.max() > 0
+    for b in range(B):
+        _, info = oracle_mod.generate_trajectory(wp[b], order=order, path_weight=0.5, vel_zero_weight=0.0, v_avg=5.0,
+                                                 min_time_s=0.1, sample_distance=1.0)
+        assert plan.iterations[b] == info["iters"], (b, plan.iterations[b], info["iters"])
+        assert abs(plan.vel_zero_weight[b] - info["vel_zero_weight"]) <= 1e-15
+        assert abs(plan.max_dev[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
+        assert np.max(np.abs(plan.coeffs[b] - info["coeff"])) < 1e-7 * np.max(np.abs(info["coeff"])), b
