@@ -68,12 +68,16 @@ bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
     return csp::fixed_supported(s.order, s.S, s.f32, d->path_weight, s.ragged, (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }
 
-// very long trajectories (256 < S <= 1024; from 17 segments with CSP_FLAG_SPAN): spans of 16 segments per
+// very long trajectories (256 < S <= 1024; from 17 segments at order 5 or with CSP_FLAG_SPAN): spans of 16 segments per
 // lane (minsnap_span.hip).  Below 257 segments the chunked kernel is faster: the span kernel re-reads its
 // inputs once per elimination step and 2048 resident waves x 34 KB do not stay in L2.
 bool use_span(const csp_minsnap_desc *d, const Shape &s) {
     if ((d->flags & CSP_FLAG_FORCE_GENERIC) || use_fixed(d, s)) return false;
-    if (s.Smax <= 256 && !(d->flags & CSP_FLAG_SPAN)) return false;
+    // order 5 (4x4 blocks) is the exception: the chunked kernel needs 392 registers there (one wave per
+    // SIMD) and loses to the span kernel from 17 segments on (measured 1.3-1.75x at S = 20..128)
+    // (with at least a wave per SIMD of span lanes: below that the chunked kernel's 4x more lanes win)
+    const bool o5_big = s.order == 5 && s.Smax > 16 && (s.B << csp::span_lanes_log2(s.Smax)) >= 65536;
+    if (s.Smax <= 256 && !(d->flags & CSP_FLAG_SPAN) && !o5_big) return false;
     return csp::span_supported(s.order, s.Smax, s.f32 && (d->flags & CSP_FLAG_F32_ARITH), d->path_weight,
                                (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
 }

@@ -68,6 +68,9 @@ def test_validation_and_dispatch_names(csp):
     assert csp.workspace_bytes(csp.make_desc(4, 100, 1024)) == 0
     assert csp.kernel_name(csp.make_desc(4, 100, 1025)) == "generic_o4_f64"
     assert csp.kernel_name(csp.make_desc(4, 100, 64, flags=csp.FLAG_SPAN)) == "span_o4_f64_l4"
+    assert csp.kernel_name(csp.make_desc(5, 40000, 40)) == "span_o5_f64_l4"      # order 5, big batch: span kernel from 17 segments
+    assert csp.kernel_name(csp.make_desc(5, 100, 40)) == "chunked_o5_f64_l16"
+    assert csp.kernel_name(csp.make_desc(5, 100, 16)) == "chunked_o5_f64_l4"
     assert csp.kernel_name(csp.make_desc(4, 100, 16, flags=csp.FLAG_SPAN)) == "fixed_o4_s16_f64"
     assert csp.kernel_name(csp.make_desc(4, 100, 1)) == "chunked_o4_f64_l1"
     assert csp.kernel_name(csp.make_desc(1, 100, 5)) == "generic_o1_f64"         # order 1 has no free derivative
