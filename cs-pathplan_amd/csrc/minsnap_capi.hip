@@ -107,12 +107,16 @@ int select_device(int device_id) {
     if (device_id >= 0) CSP_HIP(hipSetDevice(device_id));
     int cur = 0;
     CSP_HIP(hipGetDevice(&cur));
+    // the architecture check costs a property query: once per device and thread, not per call
+    static thread_local unsigned long long checked_ok = 0;
+    if (cur < 64 && ((checked_ok >> cur) & 1ull)) return CSP_OK;
     hipDeviceProp_t p;
     CSP_HIP(hipGetDeviceProperties(&p, cur));
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
         g_last_hip_error = std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only";
         return CSP_ERR_NO_DEVICE;
     }
+    if (cur < 64) checked_ok |= 1ull << cur;
     return CSP_OK;
 }
 
