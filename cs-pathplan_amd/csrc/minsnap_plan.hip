@@ -381,11 +381,12 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
 //   * candidate times are the reference's running sum (`t += dt`, :140), not k*dt -- after thousands
 //     of additions the two differ by more than the loop's 1e-12 slack -- so a window's 64 times come
 //     from 64 sequential additions captured lane by lane;
-//   * all 64 candidates are evaluated at once; the thinning inside the window is a search: with
-//     `prev` fixed, the next recorded sample is the FIRST later candidate at distance >=
-//     sample_distance (ballot + count-trailing-zeros), `prev` moves there, the lanes behind it
-//     re-test against the new `prev`, and so on -- one short step per recorded sample, none per
-//     dropped candidate;
+//   * all 64 candidates are evaluated at once; the thinning inside the window is a chain: the first
+//     candidate at distance >= sample_distance from `prev`, then from each recorded candidate the
+//     first later one far enough from IT.  Sparse windows follow the chain with one ballot +
+//     count-trailing-zeros per recorded sample; windows that record many samples first let every lane
+//     find its own successor among the next 16 candidates (LDS), after which the chain advances by
+//     register reads.  The whole chain is then stored at once (rank in the chain = output row);
 //   * the climb-rate / turn-radius statistics (:167-193) need (sample i-2, i-1, i) only: recorded
 //     samples queue up in an LDS ring and every 64 of them are processed by the 64 lanes at once.
 // Same power sums, squared-distance test and statistics formulas as the other two samplers:
@@ -393,7 +394,8 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
 template <int O, typename IO>
 __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
     constexpr int M = 2 * O;
-    __shared__ double ring[66 * 3];   // [0],[1]: the two samples before the queued batch; [2..65]: the batch
+    __shared__ double ring[130 * 3];  // [0],[1]: the two samples before the queued batch; [2..129]: the batch (<= 127)
+    __shared__ double lc[3 * 64];     // the window's candidates, for the successor look-ahead
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     int64_t seg0;
@@ -409,11 +411,11 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
     double last[3] = {0, 0, 0};   // the most recently recorded sample (wave-uniform)
     auto flush = [&]() {
         __syncthreads();
-        if (lane < nb) {
+        for (int e = lane; e < nb; e += 64) {
             double p[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { p[q] = ring[(2 + lane) * 3 + q]; st.p1[q] = ring[(1 + lane) * 3 + q]; st.p0[q] = ring[lane * 3 + q]; }
-            st.n = n - nb + lane;
+            for (int q = 0; q < 3; ++q) { p[q] = ring[(2 + e) * 3 + q]; st.p1[q] = ring[(1 + e) * 3 + q]; st.p0[q] = ring[e * 3 + q]; }
+            st.n = n - nb + e;
             st.look(p);
         }
         __syncthreads();
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
         for (int q = 0; q < 3; ++q) last[q] = p[q];
         ++n;
         ++nb;
-        if (nb == 64) flush();
+        if (nb >= 64) flush();
     };
     auto bcast = [](double v, int src) {
         const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -438,6 +440,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
         return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     };
     const double sd2 = a.keep_dist2;
+    bool dense = false;      // the previous window recorded >= 4 samples (wave-uniform)
     for (int seg = 0; seg < S; ++seg) {
         const IO *rec = (a.seg_major && !a.seg_off) ? (const IO *)a.coeffs + ((int64_t)seg * a.B + b) * 3 * M
                                                      : (const IO *)a.coeffs + (seg0 + seg) * 3 * M;
@@ -464,15 +467,67 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
             double cur[3];
             eval_poly<M>(c, t < T ? t : T, cur);
             double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
-            unsigned long long keep = __builtin_amdgcn_ballot_w64(exists && (dx * dx + dy * dy + dz * dz >= sd2));
-            while (keep != 0) {
-                const int first = __builtin_ctzll(keep);
+            const unsigned long long keep = __builtin_amdgcn_ballot_w64(exists && (dx * dx + dy * dy + dz * dz >= sd2));
+            if (keep != 0) {
+                // The recorded samples of this window form a chain: the first candidate far enough from `prev`,
+                // then from each recorded candidate l the first later one far enough from IT.
+                int l = __builtin_ctzll(keep);
+                unsigned long long kept = 0;
+                int nxt = 64;   // dense mode: my successor if it lies within the next LA lanes
+                constexpr int LA = 16;
+                if (dense) {
+                    // many samples per window: every lane finds its own successor among the next LA
+                    // candidates at once (through LDS), so the chain below advances by register reads
+                    __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 3; ++q) prev[q] = bcast(cur[q], first);
-                record(prev);
-                // the candidates behind it are now measured from the new reference point
-                dx = cur[0] - prev[0]; dy = cur[1] - prev[1]; dz = cur[2] - prev[2];
-                keep = __builtin_amdgcn_ballot_w64(exists && lane > first && (dx * dx + dy * dy + dz * dz >= sd2));
+                    for (int q = 0; q < 3; ++q) lc[q * 64 + lane] = cur[q];
+                    __syncthreads();
+                    const int E = __builtin_popcountll(__builtin_amdgcn_ballot_w64(exists));   // existing candidates are lanes 0..E-1
+                    for (int s2 = 1; s2 <= LA; ++s2) {
+                        const int m = lane + s2;
+                        if (m < E && nxt == 64) {
+                            const double ex = lc[m] - cur[0], ey = lc[64 + m] - cur[1], ez = lc[128 + m] - cur[2];
+                            if (ex * ex + ey * ey + ez * ez >= sd2) nxt = m;
+                        }
+                    }
+                }
+                for (;;) {
+                    l = __builtin_amdgcn_readfirstlane(l);
+                    kept |= 1ull << l;
+                    if (dense) {
+                        const int nx = __builtin_amdgcn_readlane(nxt, l);
+                        if (nx < 64) { l = nx; continue; }
+                    }
+                    // ballot search from candidate l (in dense mode: beyond its look-ahead)
+                    double pl[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pl[q] = bcast(cur[q], l);
+                    dx = cur[0] - pl[0]; dy = cur[1] - pl[1]; dz = cur[2] - pl[2];
+                    const unsigned long long more = __builtin_amdgcn_ballot_w64(exists && lane > l + (dense ? LA : 0) &&
+                                                                               (dx * dx + dy * dy + dz * dz >= sd2));
+                    if (more == 0) break;
+                    l = __builtin_ctzll(more);
+                }
+                // record the whole chain at once: recorded lane -> output row n + (its rank in the chain)
+                const int cnt = __builtin_popcountll(kept);
+                if ((kept >> lane) & 1ull) {
+                    const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                    if (n + rank < a.capacity) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) out[(n + rank) * 3 + q] = (IO)cur[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) ring[(2 + nb + rank) * 3 + q] = cur[q];
+                }
+                const int lastl = 63 - __builtin_clzll(kept);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { prev[q] = bcast(cur[q], lastl); last[q] = prev[q]; }
+                n += cnt;
+                nb += cnt;
+                if (nb >= 64) flush();
+                dense = cnt >= 4;
+            } else {
+                dense = false;
             }
             tb = run;   // = the accumulated time of candidate 64 of this window
         }
