@@ -457,12 +457,13 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
         if (n == 0) record(prev);
         double tb = dt;   // accumulated time of the window's first candidate
         while (tb <= t_end(T)) {
-            // the window's 64 candidate times: 64 sequential additions, lane i keeps the i-th partial sum
-            double t = tb, run = tb;
-            for (int i = 0; i < 64; ++i) {
-                if (lane == i) t = run;
-                run += dt;
+            // the window's 64 candidate times: lane L performs the first L of the 63 sequential additions
+            // (the same partial sums, in the same order, as the reference's running t)
+            double t = tb;
+            for (int i = 0; i < 63; ++i) {
+                if (lane > i) t += dt;
             }
+            const double run = bcast(t, 63) + dt;   // the accumulated time of the next window's first candidate
             const bool exists = t <= t_end(T);
             double cur[3];
             eval_poly<M>(c, t < T ? t : T, cur);
