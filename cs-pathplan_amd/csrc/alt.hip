@@ -4,7 +4,7 @@
 // problem is sequential in its sample index and parallelism comes from the batch.  The matrix is
 // never stored: row i's diagonal and two sub-diagonal entries are rebuilt from the neighbouring
 // samples while sweeping; per row the sweep keeps (l1, l2, w) in the workspace for the backward pass.
-// Not tuned (row N4): a single long problem would want a wave-cooperative cyclic reduction.
+// A single long problem would want a wave-cooperative cyclic reduction (row N4, last in SURVEY.md 8f).
 #include "../../include/csp_alt.h"
 #include "../../include/csp_minsnap.h"
 
@@ -47,31 +47,80 @@ __device__ __forceinline__ void band_row(const double *xyz, int64_t n, int64_t i
     e += -w_prev;
 }
 
+// Full-precision reciprocal (hardware seed + two Newton steps): the pivots are sums of positive weights
+// plus 1e-8, far from the ranges IEEE division's fix-ups exist for.
+__device__ __forceinline__ double rcp64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // One banded LDL^T solve.  extra_d(i) / rhs(i) supply the problem-specific diagonal and right side.
+// Rows are taken in blocks of ROWS: everything a row needs from memory (edge weights, diagonal
+// extras, right-hand sides; the stored factors on the way back) does not depend on the recurrence, so
+// a block's loads are issued together and the two-term recurrence then runs from registers with one
+// reciprocal per row -- instead of a memory round trip and two divisions per row.
 template <class D, class Rh>
 __device__ __forceinline__ void banded_solve(const double *xyz, double *ws, int64_t n, double s, double rate, D extra_d, Rh rhs) {
-    double d1 = 1.0, d2 = 1.0, l1p = 0.0, y1 = 0.0, y2 = 0.0;   // d_{i-1}, d_{i-2}, l1_{i-1}, y_{i-1}, y_{i-2}
+    constexpr int ROWS = 8;
+    double d1 = 1.0, d2 = 1.0, r1 = 1.0, r2 = 1.0, l1p = 0.0, y1 = 0.0, y2 = 0.0;   // d_{i-1}, d_{i-2}, their reciprocals, l1_{i-1}, y_{i-1}, y_{i-2}
     double w_prev = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double w_next = (i + 1 < n) ? edge_w(xyz, i, rate) : 0.0;
-        double diag, e, f;
-        band_row(xyz, n, i, s, rate, w_prev, w_next, diag, e, f);
-        diag += extra_d(i) + 1e-8;                               // tiny regularisation (:1659-1661)
-        const double l2 = (i >= 2) ? f / d2 : 0.0;
-        const double l1 = (i >= 1) ? (e - l2 * l1p * d2) / d1 : 0.0;
-        const double d = diag - l1 * l1 * d1 - l2 * l2 * d2;
-        const double y = rhs(i) - l1 * y1 - l2 * y2;
-        ws[i * 4 + 0] = l1;
-        ws[i * 4 + 1] = l2;
-        ws[i * 4 + 2] = y / d;
-        d2 = d1; d1 = d; l1p = l1; y2 = y1; y1 = y; w_prev = w_next;
+    for (int64_t i0 = 0; i0 < n; i0 += ROWS) {
+        double dg[ROWS], ee[ROWS], ff[ROWS], rr[ROWS], wn[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 + r;
+            wn[r] = (i + 1 < n) ? edge_w(xyz, i, rate) : 0.0;
+            dg[r] = (i < n) ? extra_d(i) + 1e-8 : 1.0;             // tiny regularisation (:1659-1661)
+            rr[r] = (i < n) ? rhs(i) : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 + r;
+            if (i < n) {
+                double diag, e, f;
+                band_row(xyz, n, i, s, rate, r == 0 ? w_prev : wn[r - 1], wn[r], diag, e, f);
+                dg[r] += diag; ee[r] = e; ff[r] = f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 + r;
+            if (i < n) {
+                const double l2 = (i >= 2) ? ff[r] * r2 : 0.0;
+                const double l1 = (i >= 1) ? (ee[r] - l2 * l1p * d2) * r1 : 0.0;
+                const double d = dg[r] - l1 * l1 * d1 - l2 * l2 * d2;
+                const double y = rr[r] - l1 * y1 - l2 * y2;
+                const double rd = rcp64(d);
+                ws[i * 4 + 0] = l1;
+                ws[i * 4 + 1] = l2;
+                ws[i * 4 + 2] = y * rd;
+                d2 = d1; d1 = d; r2 = r1; r1 = rd; l1p = l1; y2 = y1; y1 = y;
+            }
+        }
+        w_prev = wn[ROWS - 1];
     }
     double z1 = 0.0, z2 = 0.0, l1n = 0.0, l2n = 0.0, l2nn = 0.0;  // z_{i+1}, z_{i+2}, l1_{i+1}, l2_{i+1}, l2_{i+2}
-    for (int64_t i = n - 1; i >= 0; --i) {
-        const double z = ws[i * 4 + 2] - l1n * z1 - l2nn * z2;
-        const double l1 = ws[i * 4 + 0], l2 = ws[i * 4 + 1];
-        ws[i * 4 + 2] = z;
-        z2 = z1; z1 = z; l2nn = l2n; l1n = l1; l2n = l2;
+    for (int64_t i0 = n - 1; i0 >= 0; i0 -= ROWS) {
+        double a0[ROWS], a1[ROWS], a2[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 - r;
+            a0[r] = (i >= 0) ? ws[i * 4 + 0] : 0.0;
+            a1[r] = (i >= 0) ? ws[i * 4 + 1] : 0.0;
+            a2[r] = (i >= 0) ? ws[i * 4 + 2] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t i = i0 - r;
+            if (i >= 0) {
+                const double z = a2[r] - l1n * z1 - l2nn * z2;
+                ws[i * 4 + 2] = z;
+                z2 = z1; z1 = z; l2nn = l2n; l1n = a0[r]; l2n = a1[r];
+            }
+        }
     }
 }
 
@@ -123,8 +172,124 @@ __global__ void __launch_bounds__(64) alt_global_smooth_kernel(AltArgs a) {
     if (a.solves) a.solves[b] = solves;
 }
 
-template <typename K>
-int run(K kernel, const double *a0, const double *xyz, const int64_t *offsets, int64_t batch, const csp_alt_params *p,
+// ---- few, long problems: one WAVE per problem ------------------------------------------------------
+// What a row needs from memory and from `hypot` (edge weights, band entries, diagonal extras,
+// right-hand side) does not depend on the recurrence: the 64 lanes prepare 64 rows at once into LDS.
+// The two-term recurrence over those 64 rows is then run by every lane redundantly (broadcast LDS
+// reads, ~45 instructions per row, no cross-lane traffic); lane r keeps row r's results and the wave
+// writes them coalesced.  Same arithmetic per row as banded_solve: identical results.
+template <class D, class Rh>
+__device__ __forceinline__ void banded_solve_wave(const double *xyz, double *ws, int64_t n, double s, double rate, D extra_d, Rh rhs,
+                                                  double *lds, int lane) {
+    double d1 = 1.0, d2 = 1.0, r1 = 1.0, r2 = 1.0, l1p = 0.0, y1 = 0.0, y2 = 0.0;
+    double w_carry = 0.0;   // edge weight (i0-1, i0)
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const double wn = (i + 1 < n) ? edge_w(xyz, i, rate) : 0.0;
+        double wp = __shfl_up(wn, 1, 64);
+        if (lane == 0) wp = w_carry;
+        double diag = 0.0, e = 0.0, f = 0.0, dgv = 1.0, rv = 0.0;
+        if (i < n) {
+            band_row(xyz, n, i, s, rate, wp, wn, diag, e, f);
+            dgv = diag + (extra_d(i) + 1e-8);
+            rv = rhs(i);
+        }
+        __syncthreads();
+        lds[lane] = dgv; lds[64 + lane] = e; lds[128 + lane] = f; lds[192 + lane] = rv;
+        __syncthreads();
+        double m1 = 0.0, m2 = 0.0, m3 = 0.0;
+        const int rows = (int)((n - i0) < 64 ? (n - i0) : 64);
+        for (int r = 0; r < rows; ++r) {
+            const int64_t ii = i0 + r;
+            const double l2 = (ii >= 2) ? lds[128 + r] * r2 : 0.0;
+            const double l1 = (ii >= 1) ? (lds[64 + r] - l2 * l1p * d2) * r1 : 0.0;
+            const double d = lds[r] - l1 * l1 * d1 - l2 * l2 * d2;
+            const double y = lds[192 + r] - l1 * y1 - l2 * y2;
+            const double rd = rcp64(d);
+            if (lane == r) { m1 = l1; m2 = l2; m3 = y * rd; }
+            d2 = d1; d1 = d; r2 = r1; r1 = rd; l1p = l1; y2 = y1; y1 = y;
+        }
+        if (i < n) { ws[i * 4 + 0] = m1; ws[i * 4 + 1] = m2; ws[i * 4 + 2] = m3; }
+        w_carry = __shfl(wn, 63, 64);
+    }
+    __syncthreads();
+    double z1 = 0.0, z2 = 0.0, l1n = 0.0, l2n = 0.0, l2nn = 0.0;
+    for (int64_t i0 = n - 1; i0 >= 0; i0 -= 64) {
+        const int64_t i = i0 - lane;     // lane r holds row i0 - r
+        __syncthreads();
+        lds[lane] = (i >= 0) ? ws[i * 4 + 0] : 0.0;
+        lds[64 + lane] = (i >= 0) ? ws[i * 4 + 1] : 0.0;
+        lds[128 + lane] = (i >= 0) ? ws[i * 4 + 2] : 0.0;
+        __syncthreads();
+        double mz = 0.0;
+        const int rows = (int)((i0 + 1) < 64 ? (i0 + 1) : 64);
+        for (int r = 0; r < rows; ++r) {
+            const double z = lds[128 + r] - l1n * z1 - l2nn * z2;
+            if (lane == r) mz = z;
+            z2 = z1; z1 = z; l2nn = l2n; l1n = lds[r]; l2n = lds[64 + r];
+        }
+        if (i >= 0) ws[i * 4 + 2] = mz;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64) alt_optimize_wave_kernel(AltArgs a) {
+    __shared__ double lds[256];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) return;
+    const double *xyz = a.xyz + o * 3, *elev = a.a + o;
+    double *ws = a.ws + o * 4, *out = a.out + o;
+    const csp_alt_params p = a.p;
+    banded_solve_wave(xyz, ws, n, p.lambda_smooth, p.max_climb_rate,
+                      [&](int64_t i) { return isnan(elev[i]) ? 0.0 : p.lambda_follow; },
+                      [&](int64_t i) {
+                          if (isnan(elev[i])) return 0.0;
+                          const double safe_h = elev[i] + p.safe_distance;
+                          return p.lambda_follow * fmax(xyz[i * 3 + 2], safe_h);
+                      }, lds, lane);
+    for (int64_t i = lane; i < n; i += 64) {
+        double z = ws[i * 4 + 2];
+        if (!isnan(elev[i]) && z < elev[i] + p.safe_distance) z = elev[i] + p.safe_distance;
+        out[i] = z;
+    }
+}
+
+__global__ void __launch_bounds__(64) alt_global_smooth_wave_kernel(AltArgs a) {
+    __shared__ double lds[256];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) { if (a.solves && lane == 0) a.solves[b] = 0; return; }
+    const double *xyz = a.xyz + o * 3, *zin = a.a + o;
+    double *ws = a.ws + o * 4, *out = a.out + o;
+    const csp_alt_params p = a.p;
+    for (int64_t i = lane; i < n; i += 64) ws[i * 4 + 3] = 0.0;
+    __syncthreads();
+    int solves = 0;
+    for (int iter = 0; iter < 10; ++iter) {
+        banded_solve_wave(xyz, ws, n, p.lambda_smooth, p.max_climb_rate,
+                          [&](int64_t i) { return (i == 0 || i == n - 1) ? 1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0)
+                                                                         : (ws[i * 4 + 3] != 0.0 ? 1e8 : 0.0); },
+                          [&](int64_t i) { return (i == 0 || i == n - 1) ? (1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0)) * zin[i]
+                                                                         : (ws[i * 4 + 3] != 0.0 ? 1e8 * zin[i] : 0.0); }, lds, lane);
+        ++solves;
+        bool violation = false;
+        for (int64_t i = lane; i < n; i += 64)
+            if (ws[i * 4 + 2] < zin[i] - 1e-3 && ws[i * 4 + 3] == 0.0) { ws[i * 4 + 3] = 1.0; violation = true; }
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(violation) == 0) break;
+    }
+    for (int64_t i = lane; i < n; i += 64) out[i] = fmax(ws[i * 4 + 2], zin[i]);
+    if (a.solves && lane == 0) a.solves[b] = solves;
+}
+
+// fewer problems than this: one wave per problem (the lanes prepare 64 rows at once); more: one lane per problem
+constexpr int64_t kWaveBatch = 2048;
+
+template <typename K, typename KW>
+int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int64_t *offsets, int64_t batch, const csp_alt_params *p,
         double *out, int32_t *solves, void *workspace, size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *stream) {
     if (batch < 0 || !p || (batch > 0 && (!a0 || !xyz || !offsets || !out))) return CSP_ERR_INVALID_ARG;
     if (batch == 0) return CSP_OK;
@@ -139,7 +304,8 @@ int run(K kernel, const double *a0, const double *xyz, const int64_t *offsets, i
         if (hipMemcpyAsync(&total, offsets + batch, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return CSP_ERR_HIP;
         if (!workspace || workspace_bytes < csp_alt_workspace_bytes(total)) return CSP_ERR_WORKSPACE;
         a.a = a0; a.xyz = xyz; a.off = offsets; a.out = out; a.solves = solves; a.ws = (double *)workspace;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
+        if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
         return hipGetLastError() == hipSuccess ? CSP_OK : CSP_ERR_HIP;
     }
     const int64_t total = offsets[batch];
@@ -155,7 +321,8 @@ int run(K kernel, const double *a0, const double *xyz, const int64_t *offsets, i
         ok(hipMemcpyAsync(d_xyz, xyz, (size_t)total * 24, hipMemcpyHostToDevice, st)) &&
         ok(hipMemcpyAsync(d_off, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, st))) {
         a.a = d_a; a.xyz = d_xyz; a.off = d_off; a.out = d_out; a.solves = d_sv; a.ws = d_ws;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
+        if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
         ok(hipGetLastError());
         ok(hipMemcpyAsync(out, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, st));
         if (solves) ok(hipMemcpyAsync(solves, d_sv, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
@@ -172,13 +339,13 @@ extern "C" size_t csp_alt_workspace_bytes(int64_t total_points) { return total_p
 extern "C" int csp_alt_optimize_heights_batch(const double *xyz, const double *elev, const int64_t *offsets, int64_t batch,
                                               const csp_alt_params *params, double *out_z, void *workspace,
                                               size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
-    return run(alt_optimize_kernel, elev, xyz, offsets, batch, params, out_z, nullptr, workspace, workspace_bytes, mem_space,
+    return run(alt_optimize_kernel, alt_optimize_wave_kernel, elev, xyz, offsets, batch, params, out_z, nullptr, workspace, workspace_bytes, mem_space,
                device_id, hip_stream);
 }
 
 extern "C" int csp_alt_global_smooth_batch(const double *input_z, const double *xyz, const int64_t *offsets, int64_t batch,
                                            const csp_alt_params *params, double *out_z, int32_t *solves, void *workspace,
                                            size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
-    return run(alt_global_smooth_kernel, input_z, xyz, offsets, batch, params, out_z, solves, workspace, workspace_bytes,
+    return run(alt_global_smooth_kernel, alt_global_smooth_wave_kernel, input_z, xyz, offsets, batch, params, out_z, solves, workspace, workspace_bytes,
                mem_space, device_id, hip_stream);
 }

@@ -108,3 +108,29 @@ def test_hip_banded_ldlt_matches_oracle(csp):
         assert solves[i] == k, (n, solves[i], k)
         assert np.allclose(g[off[i]:off[i + 1]], ref, rtol=1e-6, atol=1e-4), n
         assert (g[off[i]:off[i + 1]] >= zin[off[i]:off[i + 1]]).all()
+
+
+@pytest.mark.gpu
+def test_hip_lane_and_wave_kernels_agree(csp):
+    """Fewer than 2048 problems run one wave per problem, more run one lane per problem: a large batch
+    of small problems (lane kernels) must reproduce, problem by problem, what the same problems give
+    when solved in small batches (wave kernels) -- identical arithmetic per row, so bit for bit."""
+    rng = np.random.default_rng(12)
+    B = 2300
+    sizes = rng.integers(1, 70, size=B)
+    sizes[:4] = [1, 2, 3, 200]
+    probs = [_problem(rng, int(n), with_gaps=n > 3) for n in sizes]
+    xyz = np.concatenate([p[0] for p in probs])
+    elev = np.concatenate([p[1] for p in probs])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    zin = xyz[:, 2] + rng.uniform(0, 10, len(xyz))
+    z_lane = csp.alt_optimize_heights_batch(xyz, elev, off, 1.0, 0.5, 50.0, 2.0)
+    g_lane, s_lane = csp.alt_global_smooth_batch(zin, xyz, off, 1.0, 2.0)
+    pick = [0, 1, 2, 3, 100, 1000, B - 1]
+    sub_off = np.concatenate([[0], np.cumsum(sizes[pick])]).astype(np.int64)
+    sel = np.concatenate([np.arange(off[i], off[i + 1]) for i in pick])
+    z_wave = csp.alt_optimize_heights_batch(xyz[sel], elev[sel], sub_off, 1.0, 0.5, 50.0, 2.0)
+    g_wave, s_wave = csp.alt_global_smooth_batch(zin[sel], xyz[sel], sub_off, 1.0, 2.0)
+    assert np.array_equal(z_wave, z_lane[sel])
+    assert np.array_equal(g_wave, g_lane[sel])
+    assert np.array_equal(s_wave, s_lane[pick])
