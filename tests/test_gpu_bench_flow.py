@@ -55,3 +55,15 @@ def test_bench_two_ranks_share_one_gpu():
               "--batch", "8192"], env={"CSP_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_bench_rccl_control_flow_on_one_rank():
+    """The driver's N>1 runs go through RCCL (backend "nccl"): init with a device id, barrier inside the
+    timed region, MAX all-reduce of the timings, teardown.  One rank under torch.distributed.run with
+    CSP_BENCH_FORCE_DIST=1 takes exactly that path on this one-GPU box."""
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                "--master-addr", "127.0.0.1", "--master-port", "29547",
+                "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+               env={"CSP_BENCH_FORCE_DIST": "1"})
+    assert res["n_gpus"] == 1 and res["value"] > 1e8
+    assert res["roofline"]["kernel"] == "fixed_o4_s16_f64"
