@@ -228,6 +228,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, ref, n = cpu_baseline(o, S, wp, tm, args.cpu_budget, args.path_weight, args.vel_zero_weight)
             res["cpu_baseline"] = cb
+            # SURVEY.md 8(d) also asks for the one-core figure: a short sample of the same batch
+            import oracle as _o
+            n1 = min(48, wp.shape[0])
+            t1c = time.perf_counter()
+            _o.solve_batch(o, wp[:n1], tm[:n1], path_weight=args.path_weight, vel_zero_weight=args.vel_zero_weight, nthreads=1)
+            res["cpu_baseline_one_core"] = {"value": n1 / (time.perf_counter() - t1c), "unit": "solves/s", "cores": 1, "kind": "port",
+                                            "sample": "%d trajectories of the timed batch" % n1}
             chk = min(n, 1024)
             got = out.view(S, B, 3, 2 * o).permute(1, 0, 2, 3)[:chk] if args.segment_major else out[:chk]
             res["parity_max_rel_err"] = synth.rel_err(got.cpu().numpy(), ref[:chk])
