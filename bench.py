@@ -244,6 +244,16 @@ def main():
                                        nthreads=oracle.max_threads(), long_double=True)
             res["parity_vs_long_double"] = {"hip": synth.rel_err(got[:nld].cpu().numpy(), ld),
                                             "cpu_port_fp64": synth.rel_err(ref[:nld], ld), "trajectories": nld}
+            if args.path_weight == 0.0:
+                # ... and for the "honest CPU" line: a structured CPU solver (oracle/structured_oracle.cpp: the same
+                # block-tridiagonal LDL^T, plain loops, OpenMP) on the whole batch, all host threads
+                buf = np.zeros((B, S, 3, 2 * o))
+                _o.struct_solve_batch(o, wp, tm, vel_zero_weight=args.vel_zero_weight, nthreads=_o.max_threads(), out=buf)
+                t2c = time.perf_counter()
+                _o.struct_solve_batch(o, wp, tm, vel_zero_weight=args.vel_zero_weight, nthreads=_o.max_threads(), out=buf)
+                res["cpu_structured"] = {"value": B / (time.perf_counter() - t2c), "unit": "solves/s", "cores": _o.max_threads(),
+                                         "kind": "structured CPU solver (not the reference's algorithm)",
+                                         "sample": "the whole timed batch", "max_rel_err_vs_hip": synth.rel_err(got.cpu().numpy(), buf[:chk])}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

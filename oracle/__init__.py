@@ -18,7 +18,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     """Compile dense_oracle.c (gcc) if the shared object is missing or stale."""
-    srcs = [os.path.join(_HERE, f) for f in ("dense_oracle.c", "geo_oracle.c", "alt_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("dense_oracle.c", "geo_oracle.c", "alt_oracle.c", "structured_oracle.cpp", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -41,6 +41,9 @@ def lib():
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int,
                           ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.c_int]
+        L.csp_struct_solve_batch.restype = ctypes.c_int
+        L.csp_struct_solve_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long, _dp, _dp, _dp, ctypes.c_int,
+                                             ctypes.c_double, _dp, ctypes.c_int]
         L.csp_oracle_time_alloc.restype = ctypes.c_int
         L.csp_oracle_time_alloc.argtypes = [ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double, _dp]
         L.csp_oracle_generate_trajectory.restype = ctypes.c_long
@@ -105,6 +108,21 @@ def solve_batch(order, waypoints, times, bc=None, path_weight=0.0, vel_zero_weig
     if rc:
         raise ValueError("csp_oracle_solve_batch rc=%d" % rc)
     return coeff, md
+
+
+def struct_solve_batch(order, waypoints, times, bc=None, vel_zero_weight=0.0, nthreads=1, out=None):
+    """The structured CPU solver (structured_oracle.cpp): same problem as solve_batch without the path
+    penalty, block-tridiagonal LDL^T instead of dense inverses.  Returns coeffs [B,S,3,2o]."""
+    waypoints, times = _c(waypoints), _c(times)
+    B, S = times.shape
+    assert waypoints.shape == (B, S + 1, 3)
+    bc = _c(np.zeros((1, 4, 3)) if bc is None else bc)
+    coeff = np.zeros((B, S, 3, 2 * order)) if out is None else out
+    rc = lib().csp_struct_solve_batch(order, S, B, _p(waypoints), _p(times), _p(bc), 1 if bc.shape[0] == 1 else 0,
+                                      float(vel_zero_weight), _p(coeff), int(nthreads))
+    if rc:
+        raise ValueError("csp_struct_solve_batch rc=%d" % rc)
+    return coeff
 
 
 def time_alloc(path, v_avg, min_time_s):

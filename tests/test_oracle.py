@@ -155,3 +155,22 @@ def test_time_alloc_and_generate_trajectory_match_numpy():
     # bad shape -> empty (minimum_snap.cpp:54-57)
     e, _ = oracle.generate_trajectory(P[:1], order=2)
     assert e.size == 0
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5])
+def test_structured_cpu_solver_matches_the_dense_oracle(order):
+    """oracle/structured_oracle.cpp (block-tridiagonal LDL^T on the CPU, the 'honest CPU' timing line of
+    bench.py) against the dense restatement: boundary conditions, zero-velocity weight, S = 1..16."""
+    import oracle
+    rng = np.random.default_rng(40 + order)
+    for S in (1, 2, 5, 16):
+        wp, tm = synth.make_batch(7, S, config_id=3)
+        bc = rng.normal(size=(7, 4, 3))
+        for vw in (0.0, 0.11):
+            a = oracle.struct_solve_batch(order, wp, tm, bc, vel_zero_weight=vw, nthreads=2)
+            b, _ = oracle.solve_batch(order, wp, tm, bc, vel_zero_weight=vw)
+            tol = 1e-4 if order == 5 else 1e-8      # the dense order-5 solve carries 1e-6 of its own rounding at S = 16
+            assert synth.rel_err(a, b) < tol, (order, S, vw)
+    one = oracle.struct_solve_batch(order, wp[:1], tm[:1], None)
+    ld, _ = oracle.solve_batch(order, wp[:1], tm[:1], long_double=True)
+    assert synth.rel_err(one, ld) < 1e-9
