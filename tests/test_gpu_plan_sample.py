@@ -198,3 +198,18 @@ def test_resolve_loop_on_the_generic_kernel(csp, oracle_mod):
         assert abs(plan.vel_zero_weight[b] - info["vel_zero_weight"]) <= 1e-15
         assert abs(plan.max_dev[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
         assert np.max(np.abs(plan.coeffs[b] - info["coeff"])) < 1e-7 * np.max(np.abs(info["coeff"])), b
+
+
+def test_samplers_agree_with_fp32_storage(csp):
+    """fp32 storage: the segment-parallel sampler takes its statistics inline (stored samples are rounded), the
+    wave sampler always does; all three must still agree bit for bit on samples, counts and statistics."""
+    import torch
+    wp, _ = synth.make_batch(300, 9, config_id=29)
+    plan = csp.plan_batch(torch.from_numpy((wp * 3.0).astype(np.float32)).cuda(), 5.0, 0.1, order=3)
+    assert plan.coeffs.dtype == torch.float32
+    ref = csp.sample_batch(plan.times, plan.coeffs, 0.6, 512, one_lane=True)
+    for kw in (dict(), dict(long_segments=True)):
+        got = csp.sample_batch(plan.times, plan.coeffs, 0.6, 512, **kw)
+        torch.cuda.synchronize()
+        assert got[0].dtype == torch.float32
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), kw
