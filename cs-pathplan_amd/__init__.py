@@ -6,7 +6,7 @@ The directory name carries a hyphen, so import it with
 
 This module is a thin ctypes layer over libcsp_minsnap.so (include/csp_minsnap.h).  It is used
 by tests/, bench.py and the torch.distributed sharding helper; the drop-in for the reference's
-C++ callers is the class shim in host/minimum_snap.hpp.
+C++ callers is the class shim in host/math_util/minimum_snap.hpp.
 
 There is NO CPU fallback: importing fails loudly when the HIP extension has not been built,
 and every solve call raises when no gfx950 device is visible.

@@ -74,7 +74,7 @@ def build(force=False, verbose=False, stamps=False):
 
 
 def build_host_check(out=None):
-    """Compiles the C++ class shim (host/minimum_snap.hpp, host/bezier.hpp) against the bundled
+    """Compiles the C++ class shim (host/math_util/{minimum_snap,bezier}.hpp) against the bundled
     mini matrix type and links it with the C-ABI library: the 'does the drop-in compile' check."""
     out = out or os.path.join(HERE, "host", "shim_selftest")
     src = os.path.join(HERE, "host", "shim_selftest.cpp")

@@ -52,10 +52,14 @@ hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *ite
     return hipGetLastError();
 }
 
-// Upper bound of the candidate loop `t <= T + 1e-12` (:140).  A non-finite or absurd segment time
-// (> 1e7 s) gets no candidates instead of a loop that never ends on the device (the reference would
-// spin forever on T = inf); such a trajectory is already flagged by the solve's status.
-__device__ __forceinline__ double t_end(double T) { return T <= 1.0e7 ? T + 1e-12 : -1.0; }
+// Upper bound of the candidate loop `t <= T + 1e-12` (:140).  The loop advances by dt = min(0.1, T/10),
+// so its trip count is 10 + 1e-11/T for short segments: T = 0 (two coincident waypoints with
+// min_time_s = 0, or a caller-supplied zero), a denormal T or T in (-1e-12, 0) would never leave it --
+// the reference spins on the CPU there, on the device that is a hang.  Degenerate segment times
+// (T < 1e-14: more than 1000 candidates all clamped to t = T; negative, NaN) and absurd or non-finite
+// ones (> 1e7 s) therefore get NO candidates: NaN compares false with every t.  Such a trajectory is
+// already flagged by the solve's status (non-finite coefficients or a non-positive pivot).
+__device__ __forceinline__ double t_end(double T) { return (T >= 1.0e-14 && T <= 1.0e7) ? T + 1e-12 : __builtin_nan(""); }
 
 template <int M>
 __device__ __forceinline__ void eval_poly(const double (&c)[3][M], double t, double (&out)[3]) {

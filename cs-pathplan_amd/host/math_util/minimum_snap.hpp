@@ -171,9 +171,12 @@ public:
         // sampling, thinning and statistics (:97-195) on the device; capacity = every evaluation point
         int64_t cap = 2;
         for (int i = 0; i < S; ++i) {
-            double dt = 0.1;
-            if (dt > tm[(size_t)i] / 10.0) dt = tm[(size_t)i] / 10.0;
-            cap += (int64_t)((tm[(size_t)i] + 1e-12) / dt) + 2;
+            const double T = tm[(size_t)i];
+            cap += 2;
+            // degenerate / absurd segment times get no candidates on the device (minsnap_plan.hip t_end)
+            if (!(T >= 1.0e-14 && T <= 1.0e7)) continue;
+            const double dt = T / 10.0 < 0.1 ? T / 10.0 : 0.1;
+            cap += (int64_t)((T + 1e-12) / dt);
         }
         std::vector<double> samples((size_t)cap * 3);
         int32_t count = 0;

@@ -7,15 +7,18 @@
 //   shim_selftest plan3d|planen <file>     -> reads "order pw vw V_avg min_t sample_dist n" then n
 //                                             rows "e n u"; prints the sampled ENU points
 //   shim_selftest bezier <file>            -> same input, Bezier::GenerateTrajectoryMatrix
+//   shim_selftest time3d <file> <reps>     -> wall time of one Minisnap_3D call (one flight: the reference's own
+//                                             call pattern), averaged over <reps> after 5 warm-up calls; one JSON line
 // Exit code 3 = no usable device (the shim has no CPU fallback).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <string>
 #include <vector>
 
-#include "bezier.hpp"
-#include "minimum_snap.hpp"
+#include "math_util/bezier.hpp"
+#include "math_util/minimum_snap.hpp"
 
 struct ENUPoint { double east = 0, north = 0, up = 0; };
 
@@ -86,6 +89,18 @@ int main(int argc, char **argv) {
         for (int i = 0; i < n; ++i) { route(i, 0) = wps[i].east; route(i, 1) = wps[i].north; route(i, 2) = wps[i].up; }
         csp_host::MatrixXd s = bz.GenerateTrajectoryMatrix(route, "", pl.minimum_snap.sample_distance, -1.0);
         for (long i = 0; i < s.rows(); ++i) std::printf("%.17g %.17g %.17g\n", s(i, 0), s(i, 1), s(i, 2));
+        return 0;
+    }
+    if (mode == "time3d") {
+        const int reps = argc > 3 ? std::atoi(argv[3]) : 100;
+        std::vector<ENUPoint> o;
+        for (int i = 0; i < 5; ++i) o = pl.minisnap_3d(wps, -1.0, -1.0);
+        if (o.empty()) return pl.generator_.last_status == CSP_ERR_NO_DEVICE ? 3 : 2;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) o = pl.minisnap_3d(wps, -1.0, -1.0);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::printf("{\"plan_plus_sample_us\": %.1f, \"samples\": %zu, \"resolve_iterations\": %d, \"reps\": %d}\n", us, o.size(),
+                    pl.generator_.last_iterations, reps);
         return 0;
     }
     std::vector<ENUPoint> out = (mode == "planen") ? pl.minisnap_en(wps, -1.0, -1.0) : pl.minisnap_3d(wps, -1.0, -1.0);

@@ -5,7 +5,7 @@
  * minimum-snap QP behind `TrajectoryGeneratorTool` (reference interface:
  * math_util/minimum_snap.hpp:36-63; implementation math_util/minimum_snap.cpp:22-649).
  * The reference is a C++ class with Eigen types in its signatures; a C++ shim with the same
- * class surface (cs-pathplan_amd/host/minimum_snap.hpp) forwards to the entry points below, so
+ * class surface (cs-pathplan_amd/host/math_util/minimum_snap.hpp) forwards to the entry points below, so
  * `UavPathPlanner::Minisnap_3D/Minisnap_EN` (uavPathPlanning.cpp:4401-4474) compile unchanged.
  * See INTEGRATION.md for the binding a reference maintainer would add.
  *

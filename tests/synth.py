@@ -71,3 +71,19 @@ def rel_err(got, ref):
     den = np.max(np.abs(ref), axis=1)
     den[den == 0] = 1.0
     return float(np.max(np.max(np.abs(got - ref), axis=1) / den))
+
+
+def rel_err_per_power(got, ref):
+    """Per-coefficient-power relative error: for every trajectory and every power k the scale is
+    max over (segment, axis) of |c_ref[..., k]|, so the t^(2o-1) coefficients -- many orders of
+    magnitude below the constant term, which is just the waypoint copied through -- are judged on
+    their own size.  `rel_err` above (norm-wise, the section 8d gate) is dominated by the constant term
+    and says little about the solve.  got/ref: [B,S,3,m] (or [S,3,m] for one trajectory)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.ndim == 3:
+        got, ref = got[None], ref[None]
+    got = got.reshape(ref.shape)
+    den = np.max(np.abs(ref), axis=(1, 2), keepdims=True)
+    den = np.where(den == 0.0, 1.0, den)
+    return float(np.max(np.abs(got - ref) / den))

@@ -124,3 +124,18 @@ def test_bezier_surface(exe, tmp_path):
     ref = _bezier_py(P.tolist(), 2.5, 1.0)
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+def test_f4_fixture_through_the_class_shim(exe, tmp_path):
+    """The committed F4 cases (tests/golden/F4_minisnap_en.json: ENU waypoints + MinimumSnapConfig in, sampled ENU
+    points out) through the harness that reproduces Minisnap_EN / Minisnap_3D (uavPathPlanning.cpp:4401-4474)."""
+    from tests.test_golden_r2 import load_f4
+    for c in load_f4():
+        e = c["effective"]
+        cfg = dict(order=e["order"], pw=e.get("path_weight", 0.0), vw=e.get("vel_zero_weight", 0.0), V=e["V_avg"],
+                   mt=e["min_time_s"], sd=e["sample_distance"])
+        got, _ = _run(exe, "planen" if c["mode"] == "en" else "plan3d", tmp_path, cfg, c["waypoints_enu"])
+        assert got.shape == c["result_enu"].shape, (c["name"], got.shape, c["result_enu"].shape)
+        assert np.max(np.abs(got - c["result_enu"])) < 1e-6 * np.max(np.abs(c["result_enu"])), c["name"]
+        if c["mode"] == "en":
+            assert np.all(got[:, 2] == c["waypoints_enu"][0, 2])

@@ -53,14 +53,21 @@ def test_golden_penalties(csp):
 def test_golden_readme_uav31(csp, oracle_mod):
     """README waypoints (config C1).  cond(M) reaches 1e16..1e20 in the reference's raw-time dense
     formulation, so the fp64 dense answer is itself only accurate to a few digits; the 80-bit
-    long-double oracle is the yardstick and both errors are reported."""
+    long-double oracle is the yardstick.  The gate is the PER-POWER relative error (every coefficient
+    power judged against its own magnitude: the t^7 coefficients are ~1e-14 of the constant term here,
+    and the constant term is just the waypoint copied through, so the norm-wise figure of SURVEY.md 8d
+    -- printed beside it -- is vacuous on this fixture)."""
     for c in load_cases("F2_readme_uav31.json"):
         ld, _ = oracle_mod.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], c["path_weight"],
                                  c["vel_zero_weight"], long_double=True)
+        S, m = c["segments"], 2 * c["order"]
+        ld = ld.reshape(S, 3, m)
         r = _solve_case(csp, c)
-        e_gpu = synth.rel_err(r.coeffs.reshape(1, -1), ld.reshape(1, -1))
-        e_dense = synth.rel_err(c["coeff"].reshape(1, -1), ld.reshape(1, -1))
-        print("%s cond(M)=%.1e  gpu-vs-ld %.2e  dense-fp64-vs-ld %.2e" % (c["name"], c["cond_M"], e_gpu, e_dense))
+        e_gpu = synth.rel_err_per_power(r.coeffs.reshape(S, 3, m), ld)
+        e_dense = synth.rel_err_per_power(c["coeff"], ld)
+        print("%s cond(M)=%.1e  per-power: gpu-vs-ld %.2e  dense-fp64-vs-ld %.2e   (norm-wise: %.2e / %.2e)" % (
+            c["name"], c["cond_M"], e_gpu, e_dense, synth.rel_err(r.coeffs.reshape(1, -1), ld.reshape(1, -1)),
+            synth.rel_err(c["coeff"].reshape(1, -1), ld.reshape(1, -1))))
         if c["cond_M"] < 1e12:
             assert e_gpu < NORTH_STAR_TOL, (c["name"], e_gpu)
         else:

@@ -1,0 +1,200 @@
+"""Round-2 GPU parity tests, all through the C-ABI:
+  * BASELINE config C4 at its single-GPU shard size AND at its full size on one GPU (B = 65536 x 8 = 524288,
+    S = 16, order 4): size-independent properties on the device, an oracle subsample spread over the whole
+    batch, the one-process sharded entry bit-equal with the plain call;
+  * the committed round-2 fixtures: F4 (Minisnap_EN / _3D marshalling), F5b (S = 64), F7 (near-ties of the t*
+    arg-max and of the thinning test);
+  * degenerate segment times (0, denormal, tiny negative) in the samplers: the call returns."""
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.conftest import load_cases
+from tests.test_golden_r2 import argmax_cases, load_f4, load_f7
+
+pytestmark = pytest.mark.gpu
+NORTH_STAR_TOL = 1e-6
+
+
+def _deriv_at(torch, c, t, j, order):
+    """j-th derivative of sum_i c[..., i] t^(m-1-i) at t (broadcast over the leading dims), on the device."""
+    m = 2 * order
+    pw = torch.arange(m - 1, -1, -1, device=c.device, dtype=torch.float64)
+    fac = torch.ones(m, device=c.device, dtype=torch.float64)
+    for q in range(j):
+        fac = fac * torch.clamp(pw - q, min=0.0)
+    e = torch.clamp(pw - j, min=0.0)
+    return torch.sum(c * fac * t[..., None] ** e, dim=-1)
+
+
+def test_c4_full_size_on_one_gpu(csp, oracle_mod):
+    """BASELINE C4: B = 524288 trajectories x 16 segments, order 4, fp64 -- the whole 8-GPU batch on ONE device
+    (1.9 GB of inputs + outputs, 7x the Infinity Cache)."""
+    import torch
+    B, S, o = 524288, 16, 4
+    m = 2 * o
+    wp, tm = synth.make_batch(B, S, config_id=4)
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    r = csp.solve_batch(d_wp, d_tm, order=o, want_status=True)
+    torch.cuda.synchronize()
+    assert r.kernel == "fixed_o4_s16_f64"
+    assert int(r.status.abs().max()) == 0
+    c = r.coeffs                                                 # [B,S,3,8] on the device
+    T = d_tm[:, :, None].expand(B, S, 3)
+    scale = float(d_wp.abs().max())
+    # (1) interpolation: p_k(0) == waypoint k bit for bit, p_k(T_k) = waypoint k+1
+    assert torch.equal(c[..., m - 1], d_wp[:, :-1, :])
+    assert float((_deriv_at(torch, c, T, 0, o) - d_wp[:, 1:, :]).abs().max()) < 1e-9 * scale
+    # (2) K2: derivatives 1..6 continuous at interior waypoints
+    for j in range(1, 7):
+        end = _deriv_at(torch, c[:, :-1], T[:, :-1], j, o)
+        start = _deriv_at(torch, c[:, 1:], torch.zeros_like(T[:, 1:]), j, o)
+        mag = max(float(start.abs().max()), 1.0)
+        assert float((end - start).abs().max()) < (1e-9 if j <= 3 else 1e-5) * mag, j
+        del end, start
+    # (3) zero boundary velocity / acceleration / jerk
+    for j in (1, 2, 3):
+        assert float(_deriv_at(torch, c[:, 0], torch.zeros(B, 3, device="cuda", dtype=torch.float64), j, o).abs().max()) < 1e-12
+        assert float(_deriv_at(torch, c[:, -1], T[:, -1], j, o).abs().max()) < 1e-7
+    # (4) K6 axis permutation (bit for bit) and linearity in the waypoints
+    rp = csp.solve_batch(d_wp[:, :, [2, 0, 1]].contiguous(), d_tm, order=o).coeffs
+    assert torch.equal(rp, c[:, :, [2, 0, 1], :])
+    del rp
+    r2 = csp.solve_batch(2.0 * d_wp + 3.0, d_tm, order=o).coeffs
+    exp = 2.0 * c
+    exp[..., m - 1] += 3.0
+    assert float((r2 - exp).abs().max()) < 1e-9 * float(exp.abs().max())
+    del r2, exp
+    # (5) 256 trajectories spread over the whole batch against the CPU oracle (fp64 dense and 80-bit)
+    idx = np.linspace(0, B - 1, 256).astype(np.int64)
+    ref, _ = oracle_mod.solve_batch(o, wp[idx], tm[idx], nthreads=oracle_mod.max_threads())
+    ld, _ = oracle_mod.solve_batch(o, wp[idx], tm[idx], nthreads=oracle_mod.max_threads(), long_double=True)
+    got = c[torch.from_numpy(idx).cuda()].cpu().numpy()
+    e_ref, e_ld = synth.rel_err_per_power(got, ref), synth.rel_err_per_power(got, ld)
+    print("C4 subsample: per-power rel err vs fp64 dense oracle %.2e, vs long double %.2e (norm-wise %.2e)" %
+          (e_ref, e_ld, synth.rel_err(got, ref)))
+    assert e_ref < NORTH_STAR_TOL and e_ld < 1e-8
+    # (6) the one-process sharded entry (host memory, every device of this box) reproduces the plain call bit for bit
+    full = c.cpu().numpy()
+    n = csp.device_count()
+    sh = csp.solve_batch(wp, tm, order=o, ngpu=n)
+    assert np.array_equal(sh.coeffs, full)
+    # (7) a checksum of checksums over the shards C4 would use (65536 per GPU): each shard solved on its own equals its
+    # slice of the full batch -- what the 8-rank run computes, rank by rank
+    for g in (0, 3, 7):
+        lo = g * 65536
+        part = csp.solve_batch(d_wp[lo:lo + 65536].contiguous(), d_tm[lo:lo + 65536].contiguous(), order=o).coeffs
+        assert torch.equal(part, c[lo:lo + 65536])
+
+
+def test_f5b_s64_fixtures(csp, oracle_mod):
+    for c in load_cases("F5b_ragged_s64.json"):
+        o, S = c["order"], c["segments"]
+        ld, _ = oracle_mod.solve(o, c["path"], c["vel"], c["acc"], c["time"], long_double=True)
+        ld = ld.reshape(S, 3, 2 * o)
+        for force in (False, True):
+            r = csp.solve_batch(c["path"][None], c["time"][None], c["bc"][None], order=o, force_generic=force, want_status=True)
+            e_fix, e_ld = synth.rel_err_per_power(r.coeffs[0], c["coeff"]), synth.rel_err_per_power(r.coeffs[0], ld)
+            print("%s %s: per-power vs fixture %.2e, vs long double %.2e (fixture vs long double %.2e)" %
+                  (c["name"], r.kernel, e_fix, e_ld, synth.rel_err_per_power(c["coeff"], ld)))
+            assert int(r.status[0]) == 0
+            assert e_ld < NORTH_STAR_TOL, (c["name"], r.kernel, e_ld)
+            assert e_fix < max(NORTH_STAR_TOL, 1e-13 * c["cond_M"]), (c["name"], r.kernel, e_fix)
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_f7_argmax_near_ties(csp, force_generic):
+    """The strict `>` of minimum_snap.cpp:435 on mirror samples 4 / 12 whose squared distances differ by a relative
+    1e-8 .. 1e-10: the HIP pre-solve (Hermite-basis evaluation, FMA) must fall the way the oracle falls.  A flipped
+    decision moves the coefficients by 2e-4 per power (tests/test_golden_r2.py), the gate is 1e-7."""
+    kernels = set()
+    for c in argmax_cases():
+        r = csp.solve_batch(c["path"][None], c["time"][None], c["bc"][None], order=c["order"], path_weight=c["path_weight"],
+                            vel_zero_weight=c["vel_zero_weight"], want_max_dev=True, force_generic=force_generic)
+        kernels.add(r.kernel)
+        e = synth.rel_err_per_power(r.coeffs[0], c["coeff"])
+        assert e < 1e-7, (c["name"], r.kernel, e)
+        assert abs(r.max_dev[0] - c["max_dev"]) < 1e-8 * max(1.0, c["max_dev"]), (c["name"], r.max_dev[0], c["max_dev"])
+    assert kernels == ({"generic_o4_f64"} if force_generic else {"fixedpath_o4_s3_f64"}), kernels
+
+
+@pytest.mark.parametrize("sampler", ["segment", "one_lane", "wave"])
+def test_f7_thinning_near_ties(csp, sampler):
+    """`dist >= sample_distance` (minimum_snap.cpp:145) with sample_distance exactly ON a candidate's distance
+    (exactly representable data: both sides compute the same double) and a relative 1e-10 below / above it."""
+    import torch
+    for c in load_f7():
+        cfg = c["config"]
+        P = c["waypoints"]
+        plan = csp.plan_batch(P[None], cfg["V_avg"], cfg["min_time_s"], order=cfg["order"])
+        assert not plan.status.any()
+        t, co = torch.from_numpy(plan.times).cuda(), torch.from_numpy(plan.coeffs).cuda()
+        s, n, _ = csp.sample_batch(t, co, cfg["sample_distance"], 4096, one_lane=sampler == "one_lane", long_segments=sampler == "wave")
+        torch.cuda.synchronize()
+        n = int(n[0])
+        assert n == c["n_samples"], (c["name"], sampler, n, c["n_samples"])
+        got = s[0, :n].cpu().numpy()
+        if c["kind"] == "exact":
+            assert np.array_equal(got, c["samples"]), (c["name"], sampler)
+        else:
+            assert np.max(np.abs(got - c["samples"])) < 1e-9 * np.max(np.abs(c["samples"])), (c["name"], sampler)
+
+
+def test_f4_marshalling_fixture_through_the_c_abi(csp):
+    """F4 through csp_minsnap_plan_batch + csp_minsnap_sample_batch, marshalled the way Minisnap_EN / Minisnap_3D do
+    (uavPathPlanning.cpp:4401-4474); tests/test_gpu_host_shim.py runs the same fixture through the C++ class shim."""
+    for c in load_f4():
+        P, cfg = c["waypoints_enu"], c["effective"]
+        route = P.copy()
+        if c["mode"] == "en":
+            route[:, 2] = 0.0
+        plan = csp.plan_batch(route[None], cfg["V_avg"], cfg["min_time_s"], order=cfg["order"],
+                              path_weight=cfg.get("path_weight", 0.0), vel_zero_weight=cfg.get("vel_zero_weight", 0.0))
+        assert plan.iterations[0] == c["iterations"], c["name"]
+        assert abs(plan.vel_zero_weight[0] - float.fromhex(c["vel_zero_weight_final"])) <= 1e-15
+        cap = c["n_result"] + 16
+        s, n, stats = csp.sample_batch(plan.times, plan.coeffs, cfg["sample_distance"], cap)
+        n = int(n[0])
+        got = s[0, :n].copy()
+        if c["mode"] == "en":
+            got[:, 2] = P[0, 2]
+        assert n == c["n_result"], (c["name"], n, c["n_result"])
+        assert np.max(np.abs(got - c["result_enu"])) < 1e-6 * np.max(np.abs(c["result_enu"])), c["name"]
+        mc = float.fromhex(c["max_climb_rate"])
+        assert abs(stats[0, 0] - mc) < 1e-6 * max(1.0, mc), c["name"]
+
+
+@pytest.mark.parametrize("sampler", ["segment", "one_lane", "wave"])
+def test_degenerate_segment_times_do_not_hang_the_samplers(csp, sampler):
+    """T = 0 (two coincident waypoints with min_time_s = 0), a denormal T and T in (-1e-12, 0) make the reference's
+    candidate loop `for (t = dt; t <= T + 1e-12; t += dt)` spin forever (dt = T/10); on the device that would be a
+    hang.  Such segments get no candidates (minsnap_plan.hip t_end); the solve flags the trajectory."""
+    import torch
+    B, S, o = 8, 4, 3
+    wp, tm = synth.make_batch(B, S, config_id=31)
+    tm = tm.copy()
+    tm[1, 2] = 0.0
+    tm[2, 0] = 1e-300
+    tm[3, 3] = -1e-13
+    tm[4, 1] = 5e-324
+    tm[5, 2] = float("nan")
+    tm[6, 0] = 1e-13        # legal: 110 candidates
+    r = csp.solve_batch(wp, tm, order=o, want_status=True)
+    assert r.status[0] == 0 and all(r.status[b] != 0 for b in (1, 2, 4, 5)), r.status
+    co = np.nan_to_num(r.coeffs, nan=0.0, posinf=0.0, neginf=0.0)   # sample whatever the solve produced, finite
+    s, n, _ = csp.sample_batch(torch.from_numpy(tm).cuda(), torch.from_numpy(co).cuda(), 0.5, 512,
+                               one_lane=sampler == "one_lane", long_segments=sampler == "wave")
+    torch.cuda.synchronize()
+    n = n.cpu().numpy()
+    assert (n >= 1).all() and (n <= 512).all(), n
+    # the healthy trajectories are untouched by their neighbours' bad times
+    s_ok, n_ok, _ = csp.sample_batch(torch.from_numpy(tm[:1]).cuda(), torch.from_numpy(r.coeffs[:1]).cuda(), 0.5, 512)
+    assert int(n_ok[0]) == n[0] and torch.equal(s_ok[0, :n[0]], s[0, :n[0]])
+    # plan_batch with min_time_s = 0 and coincident waypoints produces T = 0 itself
+    wp2 = wp.copy()
+    wp2[0, 2] = wp2[0, 1]
+    plan = csp.plan_batch(wp2, 5.0, 0.0, order=o)
+    assert plan.times[0, 1] == 0.0 and plan.status[0] != 0
+    co2 = np.nan_to_num(plan.coeffs, nan=0.0, posinf=0.0, neginf=0.0)
+    s2, n2, _ = csp.sample_batch(plan.times, co2, 0.5, 512)
+    assert (n2 >= 1).all()

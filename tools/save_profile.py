@@ -7,10 +7,16 @@ derives the HBM traffic figure bench.py reports in roofline.traffic:
 FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide
 (16 B/lane) coalesced read stream (MI355X_MICROARCH.md §HBM), which is this kernel's copy-in
 pattern; WRITE_SIZE is exact for 16 B/lane stores.  Collected in separate --pmc passes.
-usage: tools/save_profile.py gpurun_out/prof_<tag> profiles/<name> [batch]"""
+usage: tools/save_profile.py gpurun_out/prof_<tag> profiles/<name> [batch] [dispatch-name] [--latest]
+`dispatch-name` is what csp_minsnap_kernel_name reports (e.g. fixed_o4_s16_f64); --latest also writes
+profiles/traffic_latest.json, the file bench.py reads (together with the content hash of the kernel's sources:
+a profile of older sources is reported as stale, not as the run's traffic)."""
 import csv, glob, json, os, shutil, sys
-src, dst = sys.argv[1], sys.argv[2]
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+latest = "--latest" in sys.argv
+argv = [a for a in sys.argv if a != "--latest"]
+src, dst = argv[1], argv[2]
+batch = int(argv[3]) if len(argv) > 3 else 65536
+dispatch = argv[4] if len(argv) > 4 else None
 os.makedirs(dst, exist_ok=True)
 for sub in ("kt", "fetch", "write", "sq1", "sq2", "misc"):
     for f in glob.glob(os.path.join(src, sub, "**", "*.csv"), recursive=True):
@@ -40,9 +46,14 @@ for f in glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursiv
     for r in csv.DictReader(open(f)):
         if "minsnap" in r["Name"]:
             avg_ns, kname = float(r["AverageNs"]), r["Name"]
-out = {"batch": batch, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # headline_source_sha(): bench.py reports this traffic figure only while the kernel's sources are unchanged
+out = {"profile_dir": dst.rstrip("/"), "source_sha": bench.headline_source_sha(), "batch": batch, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
        "hbm_bytes_per_launch": (2 * fetch + write) * 1024 if fetch and write else None,
        "kernel_avg_ns_rocprof": avg_ns,
        "note": "gfx950: FETCH_SIZE doubled (wide coalesced reads); separate --pmc passes"}
+out["kernel"] = dispatch
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+if latest:
+    json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(out))
