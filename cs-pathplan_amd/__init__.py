@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = (
     "csp_minsnap_solve_batch", "csp_minsnap_solve_batch_sharded", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
-    "csp_minsnap_strerror", "csp_minsnap_last_hip_error",
+    "csp_minsnap_strerror", "csp_minsnap_last_hip_error", "csp_minsnap_release_cached_memory",
     "csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch",
     "csp_alt_workspace_bytes", "csp_alt_optimize_heights_batch", "csp_alt_global_smooth_batch",
 )
@@ -103,6 +103,14 @@ _lib.csp_minsnap_version.restype = ctypes.c_char_p
 _lib.csp_minsnap_strerror.restype = ctypes.c_char_p
 _lib.csp_minsnap_strerror.argtypes = [ctypes.c_int]
 _lib.csp_minsnap_last_hip_error.restype = ctypes.c_char_p
+
+
+_lib.csp_minsnap_release_cached_memory.restype = None
+
+
+def release_cached_memory():
+    """Frees the idle staging arenas host-memory calls keep between calls (include/csp_minsnap.h)."""
+    _lib.csp_minsnap_release_cached_memory()
 
 
 def raw_lib():

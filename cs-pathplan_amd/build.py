@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libcsp_minsnap.so")
 SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_chunked.hip", "minsnap_span.hip", "minsnap_fixed.hip", "minsnap_fixed_o2.hip", "minsnap_fixed_o3.hip",
            "minsnap_fixed_o4a.hip", "minsnap_fixed_o4b.hip", "minsnap_fixed_o5.hip",
            "minsnap_fixedpath_o2.hip", "minsnap_fixedpath_o3.hip", "minsnap_fixedpath_o4a.hip", "minsnap_fixedpath_o4b.hip", "minsnap_timealloc.hip", "minsnap_plan.hip", "geo.hip", "alt.hip"]
-HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h",
+HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_hoststage.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h",
            os.path.join("..", "..", "include", "csp_minsnap.h"), os.path.join("..", "..", "include", "csp_geo.h"), os.path.join("..", "..", "include", "csp_alt.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
@@ -82,6 +82,24 @@ def build_host_check(out=None):
            "-I", os.path.join(HERE, "host"), src, "-o", out, "-L", HERE, "-lcsp_minsnap",
            "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
     subprocess.check_call(cmd)
+    return out
+
+
+def build_tsan_check(out=None):
+    """ThreadSanitizer build of the C-ABI's host code (CPU only): minsnap_capi.hip compiled host-only with
+    -fsanitize=thread, linked with the ordinary kernel objects and host/tsan_driver.cpp.  Returns the executable;
+    tests/test_sanitizers.py runs it (exit code 66 = a data race was reported)."""
+    build()
+    out = out or os.path.join(OBJDIR, "tsan_driver")
+    tsan_obj = os.path.join(OBJDIR, "minsnap_capi_tsan.o")
+    common = ["-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=thread", "-Wno-option-ignored"]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "--offload-host-only"] + common +
+                          ["-c", os.path.join(CSRC, "minsnap_capi.hip"), "-o", tsan_obj])
+    others = [os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o") for s in SOURCES if s != "minsnap_capi.hip"]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950"] + common +
+                          ["-x", "c++", os.path.join(HERE, "host", "tsan_driver.cpp"), "-x", "none", tsan_obj] + others +
+                          ["-I", os.path.join(HERE, "..", "include"), "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
     return out
 
 

@@ -9,6 +9,7 @@
 #include "../../include/csp_minsnap.h"
 
 #include <hip/hip_runtime.h>
+#include "minsnap_hoststage.h"
 #include <cmath>
 
 namespace {
@@ -308,28 +309,21 @@ int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int
         else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
         return hipGetLastError() == hipSuccess ? CSP_OK : CSP_ERR_HIP;
     }
+    // host memory: through the device's cached staging arena (minsnap_hoststage.h), synchronous
     const int64_t total = offsets[batch];
-    double *d_a = nullptr, *d_xyz = nullptr, *d_out = nullptr, *d_ws = nullptr;
-    int64_t *d_off = nullptr;
-    int32_t *d_sv = nullptr;
-    int rc = CSP_OK;
-    auto ok = [&](hipError_t e) { if (e != hipSuccess) rc = CSP_ERR_HIP; return e == hipSuccess; };
-    if (ok(hipMalloc(&d_a, (size_t)total * 8 + 8)) && ok(hipMalloc(&d_xyz, (size_t)total * 24 + 8)) && ok(hipMalloc(&d_out, (size_t)total * 8 + 8)) &&
-        ok(hipMalloc(&d_ws, csp_alt_workspace_bytes(total) + 8)) && ok(hipMalloc(&d_off, (size_t)(batch + 1) * 8)) &&
-        ok(hipMalloc(&d_sv, (size_t)batch * 4)) &&
-        ok(hipMemcpyAsync(d_a, a0, (size_t)total * 8, hipMemcpyHostToDevice, st)) &&
-        ok(hipMemcpyAsync(d_xyz, xyz, (size_t)total * 24, hipMemcpyHostToDevice, st)) &&
-        ok(hipMemcpyAsync(d_off, offsets, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, st))) {
-        a.a = d_a; a.xyz = d_xyz; a.off = d_off; a.out = d_out; a.solves = d_sv; a.ws = d_ws;
-        if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
-        ok(hipGetLastError());
-        ok(hipMemcpyAsync(out, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, st));
-        if (solves) ok(hipMemcpyAsync(solves, d_sv, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
-        ok(hipStreamSynchronize(st));
-    }
-    (void)hipFree(d_a); (void)hipFree(d_xyz); (void)hipFree(d_out); (void)hipFree(d_ws); (void)hipFree(d_off); (void)hipFree(d_sv);
-    return rc;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    csp::HostCall hc(cur, st);
+    const size_t o_a = hc.in(a0, (size_t)total * 8), o_xyz = hc.in(xyz, (size_t)total * 24), o_off = hc.in(offsets, (size_t)(batch + 1) * 8);
+    const size_t o_out = hc.out(out, (size_t)total * 8), o_sv = hc.out(solves, (size_t)batch * 4);
+    const size_t o_ws = hc.scratch(csp_alt_workspace_bytes(total) + 8);
+    if (hc.upload() != hipSuccess) return CSP_ERR_HIP;
+    a.a = hc.ptr<const double>(o_a); a.xyz = hc.ptr<const double>(o_xyz); a.off = hc.ptr<const int64_t>(o_off);
+    a.out = hc.ptr<double>(o_out); a.solves = hc.ptr<int32_t>(o_sv); a.ws = hc.ptr<double>(o_ws);
+    if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
+    if (hipGetLastError() != hipSuccess || hc.download() != hipSuccess) return CSP_ERR_HIP;
+    return CSP_OK;
 }
 
 }  // namespace

@@ -6,6 +6,7 @@
 #include "../../include/csp_minsnap.h"
 
 #include <hip/hip_runtime.h>
+#include "minsnap_hoststage.h"
 #include <cmath>
 
 namespace {
@@ -90,20 +91,16 @@ int run(K kernel, const double *in, const double *ref, double *out, int64_t n, u
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, in, f, out, n);
         return hipGetLastError() == hipSuccess ? CSP_OK : CSP_ERR_HIP;
     }
-    double *d_in = nullptr, *d_out = nullptr;
+    // host memory: through the device's cached staging arena (minsnap_hoststage.h), synchronous
     const size_t bytes = (size_t)n * 24;
-    if (hipMalloc(&d_in, bytes) != hipSuccess || hipMalloc(&d_out, bytes) != hipSuccess) { (void)hipFree(d_in); return CSP_ERR_HIP; }
-    int rc = CSP_OK;
-    if (hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = CSP_ERR_HIP;
-    if (rc == CSP_OK) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, (const double *)d_in, f, d_out, n);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
-            rc = CSP_ERR_HIP;
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rc;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    csp::HostCall hc(cur, st);
+    const size_t o_in = hc.in(in, bytes), o_out = hc.out(out, bytes);
+    if (hc.upload() != hipSuccess) return CSP_ERR_HIP;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, hc.ptr<const double>(o_in), f, hc.ptr<double>(o_out), n);
+    if (hipGetLastError() != hipSuccess || hc.download() != hipSuccess) return CSP_ERR_HIP;
+    return CSP_OK;
 }
 
 }  // namespace

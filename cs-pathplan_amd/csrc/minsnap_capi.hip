@@ -4,6 +4,7 @@
 // error code.
 #include "../../include/csp_minsnap.h"
 #include "minsnap_launch.h"
+#include "minsnap_hoststage.h"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -71,8 +72,15 @@ bool use_fixed(const csp_minsnap_desc *d, const Shape &s) {
 // very long trajectories (256 < S <= 1024; from 17 segments at order 5 or with CSP_FLAG_SPAN): spans of 16 segments per
 // lane (minsnap_span.hip).  Below 257 segments the chunked kernel is faster: the span kernel re-reads its
 // inputs once per elimination step and 2048 resident waves x 34 KB do not stay in L2.
+// csp_minsnap_solve_batch_sharded decides span-vs-chunked ONCE from the whole batch (the order-5 rule below looks at
+// the batch size) and pins that choice for its per-device chunks, so that sharding never changes the arithmetic.
+thread_local int g_span_override = -1;   // -1: decide here; 0 / 1: decided by the caller
+
 bool use_span(const csp_minsnap_desc *d, const Shape &s) {
     if ((d->flags & CSP_FLAG_FORCE_GENERIC) || use_fixed(d, s)) return false;
+    if (g_span_override >= 0)
+        return g_span_override == 1 && csp::span_supported(s.order, s.Smax, s.f32 && (d->flags & CSP_FLAG_F32_ARITH), d->path_weight,
+                                                           (d->flags & CSP_FLAG_SEGMENT_MAJOR) != 0);
     // order 5 (4x4 blocks) is the exception: the chunked kernel needs 392 registers there (one wave per
     // SIMD) and loses to the span kernel from 17 segments on (measured 1.3-1.75x at S = 20..128)
     // (with at least a wave per SIMD of span lanes: below that the chunked kernel's 4x more lanes win)
@@ -120,6 +128,12 @@ int select_device(int device_id) {
     return CSP_OK;
 }
 
+int current_device() {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    return cur;
+}
+
 // Smallest double x with sqrt(x) >= d under IEEE rounding (sqrt is monotone), so that the kernels can
 // test the squared distance: d2 >= x  <=>  sqrt(d2) >= d.  d <= 0 keeps everything (x = 0), NaN nothing.
 double keep_threshold(double d) {
@@ -132,12 +146,6 @@ double keep_threshold(double d) {
     while (std::sqrt(x) < d) x = std::nextafter(x, std::numeric_limits<double>::infinity());
     return x;
 }
-
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { CSP_HIP(hipMalloc(&p, n ? n : 1)); return CSP_OK; }
-};
 
 int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const void *tm, const void *bc,
              void *co, double *max_dev, int32_t *status, const int64_t *seg_off, const double *vw_per,
@@ -248,7 +256,7 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
         return dispatch(desc, s, waypoints, times, bc, coeffs, max_dev, status, desc->seg_offsets,
                         desc->vel_zero_weight_per_traj, workspace, workspace_bytes, st);
 
-    // CSP_MEM_HOST: stage through the device, synchronously.
+    // CSP_MEM_HOST: stage through a cached per-device arena (minsnap_hoststage.h), synchronously.
     int64_t total_seg;
     if (s.ragged) {
         total_seg = desc->seg_offsets[s.B];
@@ -264,30 +272,19 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
     const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt;
     const size_t n_co = (size_t)total_seg * 3 * m * s.elt;
     const size_t n_ws = ws_bytes(desc, s, nullptr);
-    DevBuf d_wp, d_tm, d_bc, d_co, d_md, d_st, d_so, d_vw, d_ws;
-    if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm)) || (rc = d_bc.alloc(n_bc)) ||
-        (rc = d_co.alloc(n_co)) || (rc = d_ws.alloc(n_ws)))
-        return rc;
-    if (max_dev && (rc = d_md.alloc((size_t)s.B * 8))) return rc;
-    if (status && (rc = d_st.alloc((size_t)s.B * 4))) return rc;
-    CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
-    CSP_HIP(hipMemcpyAsync(d_tm.p, times, n_tm, hipMemcpyHostToDevice, st));
-    CSP_HIP(hipMemcpyAsync(d_bc.p, bc, n_bc, hipMemcpyHostToDevice, st));
-    if (s.ragged) {
-        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
-        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
-    }
-    if (desc->vel_zero_weight_per_traj) {
-        if ((rc = d_vw.alloc((size_t)s.B * 8))) return rc;
-        CSP_HIP(hipMemcpyAsync(d_vw.p, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyHostToDevice, st));
-    }
-    rc = dispatch(desc, s, d_wp.p, d_tm.p, d_bc.p, d_co.p, (double *)d_md.p, (int32_t *)d_st.p,
-                  (const int64_t *)d_so.p, (const double *)d_vw.p, d_ws.p, n_ws, st);
+    csp::HostCall hc(current_device(), st);
+    const size_t o_wp = hc.in(waypoints, n_wp), o_tm = hc.in(times, n_tm), o_bc = hc.in(bc, n_bc);
+    const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_vw = desc->vel_zero_weight_per_traj ? hc.in(desc->vel_zero_weight_per_traj, (size_t)s.B * 8) : 0;
+    const size_t o_co = hc.out(coeffs, n_co);
+    const size_t o_md = max_dev ? hc.out(max_dev, (size_t)s.B * 8) : 0, o_st = status ? hc.out(status, (size_t)s.B * 4) : 0;
+    const size_t o_ws = hc.scratch(n_ws);
+    CSP_HIP(hc.upload());
+    rc = dispatch(desc, s, hc.ptr(o_wp), hc.ptr(o_tm), hc.ptr(o_bc), hc.ptr(o_co), max_dev ? hc.ptr<double>(o_md) : nullptr,
+                  status ? hc.ptr<int32_t>(o_st) : nullptr, s.ragged ? hc.ptr<const int64_t>(o_so) : nullptr,
+                  desc->vel_zero_weight_per_traj ? hc.ptr<const double>(o_vw) : nullptr, hc.ptr(o_ws), n_ws, st);
     if (rc != CSP_OK) return rc;
-    CSP_HIP(hipMemcpyAsync(coeffs, d_co.p, n_co, hipMemcpyDeviceToHost, st));
-    if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, d_md.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
-    if (status) CSP_HIP(hipMemcpyAsync(status, d_st.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
-    CSP_HIP(hipStreamSynchronize(st));
+    CSP_HIP(hc.download());
     return CSP_OK;
 }
 
@@ -299,11 +296,22 @@ int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *wa
     if (desc->mem_space != CSP_MEM_HOST || (desc->flags & CSP_FLAG_SEGMENT_MAJOR)) return CSP_ERR_INVALID_ARG;
     if (s.B == 0) return CSP_OK;
     if (!waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
-    const int have = csp_minsnap_device_count();
+    // chunk g runs on the g-th gfx950 device (other architectures may sit between them in HIP's numbering)
+    std::vector<int> ordinals;
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        for (int i = 0; i < n; ++i) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ordinals.push_back(i);
+        }
+    }
+    const int have = (int)ordinals.size();
     if (have <= 0) return CSP_ERR_NO_DEVICE;
     if (ngpu <= 0) ngpu = have;
     if (ngpu > have) return CSP_ERR_INVALID_ARG;
     if ((int64_t)ngpu > s.B) ngpu = (int)s.B;
+    const int span_choice = use_span(desc, s) ? 1 : 0;   // from the WHOLE batch; pinned for every chunk
     const size_t m = 2 * (size_t)s.order;
     struct Chunk {
         csp_minsnap_desc d;
@@ -319,7 +327,7 @@ int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *wa
         Chunk &c = ch[(size_t)g];
         c.d = *desc;
         c.d.batch = hi - lo;
-        c.d.device_id = g;
+        c.d.device_id = ordinals[(size_t)g];
         if (s.ragged) {
             c.off.resize((size_t)(hi - lo + 1));
             for (int64_t b = lo; b <= hi; ++b) c.off[(size_t)(b - lo)] = desc->seg_offsets[b] - seg_lo;
@@ -332,9 +340,19 @@ int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *wa
         char *co = (char *)coeffs + (size_t)seg_lo * 3 * m * s.elt;
         double *md = max_dev ? max_dev + lo : nullptr;
         int32_t *stt = status ? status + lo : nullptr;
-        th.emplace_back([&c, wp, tm, bcp, co, md, stt]() {
-            c.rc = csp_minsnap_solve_batch(&c.d, wp, tm, bcp, co, md, stt, nullptr, 0, nullptr);
+        // one host thread per device: each stages its chunk through that device's cached arena (pinned halves,
+        // DMA overlapped with the CPU copy) on a stream of its own, so the devices' transfers and kernels overlap
+        th.emplace_back([&c, wp, tm, bcp, co, md, stt, span_choice]() {
+            g_span_override = span_choice;
+            hipStream_t st = nullptr;
+            if (hipSetDevice(c.d.device_id) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                c.rc = CSP_ERR_HIP;
+                c.err = "hipSetDevice / hipStreamCreate failed in a shard worker";
+                return;
+            }
+            c.rc = csp_minsnap_solve_batch(&c.d, wp, tm, bcp, co, md, stt, nullptr, 0, st);
             if (c.rc != CSP_OK) c.err = g_last_hip_error;   // the worker's thread-local text
+            (void)hipStreamDestroy(st);
         });
     }
     for (auto &t : th) t.join();
@@ -362,18 +380,15 @@ int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypo
     }
     const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
     const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
-    DevBuf d_wp, d_tm, d_so;
-    if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm))) return rc;
-    CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
-    if (s.ragged) {
-        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
-        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
-    }
-    a.wp = d_wp.p; a.times = d_tm.p; a.seg_off = (const int64_t *)d_so.p;
+    csp::HostCall hc(current_device(), st);
+    const size_t o_wp = hc.in(waypoints, n_wp);
+    const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_tm = hc.out(times, n_tm);
+    CSP_HIP(hc.upload());
+    a.wp = hc.ptr(o_wp); a.times = hc.ptr(o_tm); a.seg_off = s.ragged ? hc.ptr<const int64_t>(o_so) : nullptr;
     hipError_t e = csp::launch_time_alloc(a, s.f32, st);
     if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
-    CSP_HIP(hipMemcpyAsync(times, d_tm.p, n_tm, hipMemcpyDeviceToHost, st));
-    CSP_HIP(hipStreamSynchronize(st));
+    CSP_HIP(hc.download());
     return CSP_OK;
 }
 
@@ -383,60 +398,24 @@ size_t csp_minsnap_plan_workspace_bytes(const csp_minsnap_desc *desc) {
     csp_minsnap_desc g = *desc;
     Shape gs;
     validate(&g, gs);
-    // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32 + t* indices [S][B] i32 (path kernel)
+    // solve workspace + vw[B] f64 + max_dev[B] f64 + iters[B] i32 + done[B] i32 + the count of unfinished trajectories (i32)
+    // + t* indices [S][B] i32 (path kernel)
     const size_t tau = (desc->path_weight > 0.0 && use_fixed(&g, gs)) ? align_up((size_t)s.B * (size_t)s.S * 4, 256) : 0;
-    return align_up(ws_bytes(&g, gs, nullptr), 256) + align_up((size_t)s.B * 8, 256) * 2 + align_up((size_t)s.B * 4, 256) * 2 + tau;
+    return align_up(ws_bytes(&g, gs, nullptr), 256) + align_up((size_t)s.B * 8, 256) * 2 + align_up((size_t)s.B * 4, 256) * 2 + 256 + tau;
 }
 
-int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
-                           const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
-                           int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes,
-                           void *hip_stream) {
-    Shape s;
-    int rc = validate(desc, s);
-    if (rc != CSP_OK) return rc;
-    if (s.B == 0) return CSP_OK;
-    if (!waypoints || !bc || !times || !coeffs) return CSP_ERR_INVALID_ARG;
-    rc = select_device(desc->device_id);
-    if (rc != CSP_OK) return rc;
-    hipStream_t st = (hipStream_t)hip_stream;
+}  // extern "C"
 
-    if (desc->mem_space == CSP_MEM_HOST) {
-        // stage through the device, then run the device-memory form
-        const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
-        const size_t m = 2 * (size_t)s.order;
-        const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
-        const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
-        DevBuf d_wp, d_tm, d_bc, d_co, d_md, d_vw, d_it, d_st, d_so, d_ws;
-        csp_minsnap_desc dd = *desc;
-        dd.mem_space = CSP_MEM_DEVICE;
-        const size_t n_ws = csp_minsnap_plan_workspace_bytes(&dd);
-        if ((rc = d_wp.alloc(n_wp)) || (rc = d_tm.alloc(n_tm)) || (rc = d_bc.alloc(n_bc)) || (rc = d_co.alloc(n_co)) ||
-            (rc = d_md.alloc((size_t)s.B * 8)) || (rc = d_vw.alloc((size_t)s.B * 8)) || (rc = d_it.alloc((size_t)s.B * 4)) ||
-            (rc = d_st.alloc((size_t)s.B * 4)) || (rc = d_ws.alloc(n_ws)))
-            return rc;
-        CSP_HIP(hipMemcpyAsync(d_wp.p, waypoints, n_wp, hipMemcpyHostToDevice, st));
-        CSP_HIP(hipMemcpyAsync(d_bc.p, bc, n_bc, hipMemcpyHostToDevice, st));
-        if (s.ragged) {
-            if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
-            CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
-            dd.seg_offsets = (const int64_t *)d_so.p;
-        }
-        dd.vel_zero_weight_per_traj = nullptr;
-        rc = csp_minsnap_plan_batch(&dd, d_wp.p, v_avg, min_time_s, d_bc.p, d_tm.p, d_co.p, (double *)d_md.p,
-                                    (double *)d_vw.p, (int32_t *)d_it.p, (int32_t *)d_st.p, d_ws.p, n_ws, st);
-        if (rc != CSP_OK) return rc;
-        CSP_HIP(hipMemcpyAsync(times, d_tm.p, n_tm, hipMemcpyDeviceToHost, st));
-        CSP_HIP(hipMemcpyAsync(coeffs, d_co.p, n_co, hipMemcpyDeviceToHost, st));
-        if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, d_md.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
-        if (vel_zero_weight_out) CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, d_vw.p, (size_t)s.B * 8, hipMemcpyDeviceToHost, st));
-        if (iterations) CSP_HIP(hipMemcpyAsync(iterations, d_it.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
-        if (status) CSP_HIP(hipMemcpyAsync(status, d_st.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
-        CSP_HIP(hipStreamSynchronize(st));
-        return CSP_OK;
-    }
+namespace {
 
-    // ---- device memory ----
+// Device-memory form of csp_minsnap_plan_batch.  `sync_early_exit`: the CSP_MEM_HOST wrapper is synchronous anyway, so it
+// reads the count of unfinished trajectories after every pass and stops the <= 11-pass loop as soon as it is zero (one
+// flight usually converges at its first solve: ten solves saved); device-memory callers get the fully asynchronous form.
+int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoints, double v_avg, double min_time_s,
+                const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
+                int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes, hipStream_t st,
+                bool sync_early_exit) {
+    int rc;
     csp::TimeAllocArgs ta;
     ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
     ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
@@ -470,6 +449,7 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
     double *md = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
     int32_t *iters = (int32_t *)base;                             base += align_up((size_t)s.B * 4, 256);
     int32_t *done = (int32_t *)base;                              base += align_up((size_t)s.B * 4, 256);
+    int32_t *pending = (int32_t *)base;                           base += 256;
     // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
     int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
     if ((e = csp::launch_resolve_init(vw, iters, done, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
@@ -479,11 +459,65 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
         rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done,
                       tau_buf, pass == 0 ? 1 : 2);
         if (rc != CSP_OK) return rc;
-        if ((e = csp::launch_resolve_update(md, vw, iters, done, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_update");
+        if (sync_early_exit) CSP_HIP(hipMemsetAsync(pending, 0, 4, st));
+        if ((e = csp::launch_resolve_update(md, vw, iters, done, sync_early_exit ? pending : nullptr, s.B, st)) != hipSuccess)
+            return hip_fail(e, "resolve_update");
+        if (sync_early_exit) {
+            int32_t left = 0;
+            CSP_HIP(hipMemcpyAsync(&left, pending, 4, hipMemcpyDeviceToHost, st));
+            CSP_HIP(hipStreamSynchronize(st));
+            if (left == 0) break;
+        }
     }
     if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, md, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     if (vel_zero_weight_out) CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, vw, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     if (iterations) CSP_HIP(hipMemcpyAsync(iterations, iters, (size_t)s.B * 4, hipMemcpyDeviceToDevice, st));
+    return CSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
+                           const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
+                           int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes,
+                           void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !bc || !times || !coeffs) return CSP_ERR_INVALID_ARG;
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (desc->mem_space == CSP_MEM_DEVICE)
+        return plan_device(desc, s, waypoints, v_avg, min_time_s, bc, times, coeffs, max_dev, vel_zero_weight_out, iterations,
+                           status, workspace, workspace_bytes, st, false);
+
+    // CSP_MEM_HOST: stage through the device's cached arena, then run the device-memory form
+    const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    const size_t m = 2 * (size_t)s.order;
+    const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
+    const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
+    csp_minsnap_desc dd = *desc;
+    dd.mem_space = CSP_MEM_DEVICE;
+    const size_t n_ws = csp_minsnap_plan_workspace_bytes(&dd);
+    csp::HostCall hc(current_device(), st);
+    const size_t o_wp = hc.in(waypoints, n_wp), o_bc = hc.in(bc, n_bc);
+    const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_vi = desc->vel_zero_weight_per_traj ? hc.in(desc->vel_zero_weight_per_traj, (size_t)s.B * 8) : 0;
+    const size_t o_tm = hc.out(times, n_tm), o_co = hc.out(coeffs, n_co);
+    const size_t o_md = hc.out(max_dev, (size_t)s.B * 8), o_vw = hc.out(vel_zero_weight_out, (size_t)s.B * 8);
+    const size_t o_it = hc.out(iterations, (size_t)s.B * 4), o_st = hc.out(status, (size_t)s.B * 4);
+    const size_t o_ws = hc.scratch(n_ws);
+    CSP_HIP(hc.upload());
+    if (s.ragged) dd.seg_offsets = hc.ptr<const int64_t>(o_so);
+    dd.vel_zero_weight_per_traj = desc->vel_zero_weight_per_traj ? hc.ptr<const double>(o_vi) : nullptr;
+    rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
+                     hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true);
+    if (rc != CSP_OK) return rc;
+    CSP_HIP(hc.download());
     return CSP_OK;
 }
 
@@ -525,25 +559,30 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     const size_t m = 2 * (size_t)s.order;
     const size_t n_tm = (size_t)total_seg * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
     const size_t n_sm = (size_t)s.B * (size_t)capacity * 3 * s.elt;
-    DevBuf d_tm, d_co, d_sm, d_ct, d_sx, d_so;
-    if ((rc = d_tm.alloc(n_tm)) || (rc = d_co.alloc(n_co)) || (rc = d_sm.alloc(n_sm)) || (rc = d_ct.alloc((size_t)s.B * 4)) ||
-        (rc = d_sx.alloc((size_t)s.B * 16)))
-        return rc;
-    CSP_HIP(hipMemcpyAsync(d_tm.p, times, n_tm, hipMemcpyHostToDevice, st));
-    CSP_HIP(hipMemcpyAsync(d_co.p, coeffs, n_co, hipMemcpyHostToDevice, st));
-    if (s.ragged) {
-        if ((rc = d_so.alloc((size_t)(s.B + 1) * 8))) return rc;
-        CSP_HIP(hipMemcpyAsync(d_so.p, desc->seg_offsets, (size_t)(s.B + 1) * 8, hipMemcpyHostToDevice, st));
-    }
-    a.times = d_tm.p; a.coeffs = d_co.p; a.seg_off = (const int64_t *)d_so.p;
-    a.samples = d_sm.p; a.counts = (int32_t *)d_ct.p; a.stats = (double *)d_sx.p;
+    csp::HostCall hc(current_device(), st);
+    const size_t o_tm = hc.in(times, n_tm), o_co = hc.in(coeffs, n_co);
+    const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_ct = hc.out(counts, (size_t)s.B * 4), o_sx = hc.out(stats, (size_t)s.B * 16);
+    const size_t o_sm = hc.out(s.B == 1 ? nullptr : samples, n_sm);   // one flight: copied back below, only the rows in use
+    CSP_HIP(hc.upload());
+    a.times = hc.ptr(o_tm); a.coeffs = hc.ptr(o_co); a.seg_off = s.ragged ? hc.ptr<const int64_t>(o_so) : nullptr;
+    a.samples = hc.ptr(o_sm); a.counts = hc.ptr<int32_t>(o_ct); a.stats = hc.ptr<double>(o_sx);
     hipError_t e = csp::launch_sample(a, s.f32, st);
     if (e != hipSuccess) return hip_fail(e, "sample launch");
-    CSP_HIP(hipMemcpyAsync(samples, d_sm.p, n_sm, hipMemcpyDeviceToHost, st));
-    CSP_HIP(hipMemcpyAsync(counts, d_ct.p, (size_t)s.B * 4, hipMemcpyDeviceToHost, st));
-    if (stats) CSP_HIP(hipMemcpyAsync(stats, d_sx.p, (size_t)s.B * 16, hipMemcpyDeviceToHost, st));
-    CSP_HIP(hipStreamSynchronize(st));
+    if (s.B == 1) {
+        // one flight: `capacity` is an upper bound (every candidate); fetch the count first and then only the rows in use
+        CSP_HIP(hipMemcpyAsync(counts, hc.ptr(o_ct), 4, hipMemcpyDeviceToHost, st));
+        CSP_HIP(hipStreamSynchronize(st));
+        const int64_t rows = counts[0] < capacity ? (counts[0] > 0 ? counts[0] : 0) : capacity;
+        if (rows) CSP_HIP(hipMemcpyAsync(samples, hc.ptr(o_sm), (size_t)rows * 3 * s.elt, hipMemcpyDeviceToHost, st));
+        if (stats) CSP_HIP(hipMemcpyAsync(stats, hc.ptr(o_sx), 16, hipMemcpyDeviceToHost, st));
+        CSP_HIP(hipStreamSynchronize(st));
+        return CSP_OK;
+    }
+    CSP_HIP(hc.download());
     return CSP_OK;
 }
+
+void csp_minsnap_release_cached_memory(void) { csp::arena_free_idle(); }
 
 }  // extern "C"

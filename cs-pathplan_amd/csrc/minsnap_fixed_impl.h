@@ -19,6 +19,7 @@
 #include "minsnap_device.h"
 #include "minsnap_launch.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #ifdef CSP_STAMPS
@@ -239,7 +240,7 @@ template <bool BOTTOM> struct RoleBc {
 template <int O, int S, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
                                            const In &in, const RoleBc<BOTTOM> &rbc, double *stage, double *partner_stage,
-                                           double *tst, const Hook &after_exchange) {
+                                           double *tst, const Hook &after_exchange, int rows = 64) {
     constexpr int N = O - 1, M = 2 * O;
     constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;   // segments of THIS role; both roles meet at waypoint ceil(S/2)
     using L = FixedLds<O, S>;
@@ -504,7 +505,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
                 for (int i = 0; i < L::NI; ++i) {
                     const int row = i * L::RPI + grp;
-                    if (lane < L::RPI * L::LPR && row < 64 && b0 + row < a.B) {
+                    if (lane < L::RPI * L::LPR && row < rows) {
                         const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
                         *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v2;
                     }
@@ -519,7 +520,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     }
     CSP_STAMP(4);
     CSP_STAMP_RT(6);
-    if (STATUS && b0 + lane < a.B) {
+    if (STATUS && lane < rows) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
     }
@@ -538,8 +539,11 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int role = tid >> 6;  // wave-uniform
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
-    const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    // FULL: 64 trajectories per workgroup; otherwise a.slice_w (<= 64) of them -- the ragged tail of a batch, or a small
+    // batch cut into narrow slices (lanes >= rows compute on an unloaded image and store nothing)
+    const int slice_w = FULL ? 64 : a.slice_w;
+    const int64_t b0 = (int64_t)blockIdx.x * slice_w;
+    const int rows = (int)((a.B - b0) < slice_w ? (a.B - b0) : slice_w);
 
     CSP_STAMP_RT(5);
     CSP_STAMP(0);
@@ -577,12 +581,12 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
         const LdsInputs<S, false> in{l_wp, l_tm, lane};
         RoleBc<false> rbc;
         rbc.load(a, b);
-        fixed_body<O, S, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{});
+        fixed_body<O, S, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{}, rows);
     } else {
         const LdsInputs<S, true> in{l_wp, l_tm, lane};
         RoleBc<true> rbc;
         rbc.load(a, b);
-        fixed_body<O, S, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{});
+        fixed_body<O, S, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{}, rows);
     }
 }
 
@@ -697,11 +701,34 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
 }
 
 // ---- host side: launch one order's kernels -----------------------------------------------------
+// Trajectories per workgroup for the one-workgroup-per-slice kernel: halve from 64 while the batch would leave CUs
+// without a workgroup (two per CU fit), not below 8.  CSP_SLICE_W overrides (tuning experiments).
+inline int narrow_slice(int64_t B, int cus) {
+    static const int forced = [] { const char *e = std::getenv("CSP_SLICE_W"); return e ? std::atoi(e) : 0; }();
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;   // even: 16-byte pieces stay aligned
+    static const int per_cu = [] { const char *e = std::getenv("CSP_SLICE_PER_CU"); return e ? std::atoi(e) : 1; }();
+    int w = 64;
+    while (w > 8 && (B + w - 1) / w < (per_cu > 0 ? per_cu : 1) * (int64_t)cus) w >>= 1;
+    return w;
+}
+
 // SEGMAJ_OK: whether the segment-major layout is instantiated for this order (order 4 only).
 template <int O, int S, bool SEGMAJ_OK>
 hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
-    const int64_t n_full = a.B / 64, rem = a.B % 64;
     const dim3 block(128);
+    // A small batch (fewer 64-trajectory slices than two workgroups per CU) is latency-bound, and what a workgroup
+    // moves through ONE CU's memory path is on that latency: cut it into narrower slices so that every CU gets a
+    // workgroup (C2: B = 4096 -> 512 workgroups of 8 instead of 64 of 64).
+    const int w = narrow_slice(a.B, cus);
+    if (w < 64 && !a.seg_major) {
+        GenericArgs t = a;
+        t.slice_w = w;
+        const dim3 grid((unsigned)((a.B + w - 1) / w));
+        if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false>), grid, block, 0, st, t);
+        else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false>), grid, block, 0, st, t);
+        return hipGetLastError();
+    }
+    const int64_t n_full = a.B / 64, rem = a.B % 64;
     const int64_t pgrid = n_full < 2 * (int64_t)cus ? n_full : 2 * (int64_t)cus;  // two workgroups per CU
     GenericArgs t = a;  // tail: the last B % 64 trajectories, one workgroup
     if (rem) {

@@ -32,6 +32,8 @@ struct GenericArgs {
     int persistent;         // fixed kernel: persistent workgroups with LDS-DMA prefetch (default on)
     const int32_t *skip;    // generic kernel: [B] non-zero = leave this trajectory untouched (or null)
     int tau_mode;           // path kernel: 0 find t* each call; 1 find and store in tstar; 2 reuse tstar (re-solve loop)
+    int slice_w = 64;       // fixed kernels, one-workgroup-per-slice variant: trajectories per workgroup (small batches
+                            // are cut into narrower slices so that every CU gets one, see fixedk::narrow_slice)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
@@ -68,7 +70,8 @@ hipError_t launch_time_alloc(const TimeAllocArgs &a, bool f32, hipStream_t st);
 // Re-solve loop bookkeeping (minimum_snap.cpp:80-90) and polynomial sampling (:97-205), minsnap_plan.hip
 hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, double vw0, int64_t B, hipStream_t st);
 hipError_t launch_fill_f64(double *p, double v, int64_t n, hipStream_t st);
-hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int64_t B, hipStream_t st);
+hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int32_t *pending, int64_t B,
+                                 hipStream_t st);
 struct SampleArgs {
     const void *times, *coeffs;
     const int64_t *seg_off;

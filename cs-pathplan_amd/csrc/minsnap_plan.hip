@@ -19,13 +19,14 @@ __global__ void __launch_bounds__(256) resolve_init_kernel(double *vw, int32_t *
 }
 
 __global__ void __launch_bounds__(256) resolve_update_kernel(const double *max_dev, double *vw, int32_t *iters,
-                                                             int32_t *done, int64_t B) {
+                                                             int32_t *done, int32_t *pending, int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || done[b]) return;
     if (max_dev[b] > 0.2 && iters[b] < 10) {
         const double w = vw[b];
         vw[b] = (w < 1e-6) ? 0.01 : w * 2.0;
         iters[b] += 1;
+        if (pending) atomicAdd(pending, 1);   // host-memory callers stop the loop when nobody is left (capi plan_device)
     } else {
         done[b] = 1;
     }
@@ -46,9 +47,10 @@ hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, double
     hipLaunchKernelGGL(resolve_init_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, vw, iters, done, vw0, B);
     return hipGetLastError();
 }
-hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int64_t B, hipStream_t st) {
+hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int32_t *pending, int64_t B,
+                                 hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(resolve_update_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, max_dev, vw, iters, done, B);
+    hipLaunchKernelGGL(resolve_update_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, max_dev, vw, iters, done, pending, B);
     return hipGetLastError();
 }
 

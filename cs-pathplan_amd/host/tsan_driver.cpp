@@ -1,0 +1,64 @@
+// tsan_driver.cpp -- ThreadSanitizer run of the C-ABI's HOST code (CPU only -- the GPU pool allows
+// no sanitizers).  Built by cs-pathplan_amd/build.py::build_tsan_check(): minsnap_capi.hip compiled host-only with
+// -fsanitize=thread, linked with the ordinary kernel objects, plus this driver.  Without a device every compute entry
+// returns CSP_ERR_NO_DEVICE after its validation and device probing, which is the code that runs here: argument
+// validation, kernel selection / naming (thread-local buffers), the thread-local HIP error text, the sharded entry's
+// device enumeration, and the staging-arena pool (mutex-protected free lists shared by all threads of a process).
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "csp_minsnap.h"
+#include "../csrc/minsnap_hoststage.h"
+
+static std::atomic<int> failures{0};
+
+static void worker(int id) {
+    double wp[(16 + 1) * 3 * 4] = {0}, tm[16 * 4], bc[12] = {0}, co[16 * 3 * 10 * 4];
+    for (double &t : tm) t = 1.0;
+    for (int it = 0; it < 400; ++it) {
+        csp_minsnap_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.abi_version = CSP_MINSNAP_ABI_VERSION;
+        d.dtype = (it & 1) ? CSP_DTYPE_F32 : CSP_DTYPE_F64;
+        d.order = 1 + (it + id) % 5;
+        d.num_segments = 1 + (it * 7 + id) % 16;
+        d.batch = 1 + (it % 4);
+        d.mem_space = CSP_MEM_HOST;
+        d.device_id = -1;
+        d.path_weight = (it % 3 == 0) ? 0.1 : 0.0;
+        const char *name = csp_minsnap_kernel_name(&d);
+        if (!name || !*name) ++failures;
+        (void)csp_minsnap_workspace_bytes(&d);
+        (void)csp_minsnap_plan_workspace_bytes(&d);
+        int rc = csp_minsnap_solve_batch(&d, wp, tm, bc, co, nullptr, nullptr, nullptr, 0, nullptr);
+        if (rc != CSP_ERR_NO_DEVICE && rc != CSP_OK) ++failures;           // no silent CPU fallback, no other error
+        rc = csp_minsnap_solve_batch_sharded(&d, wp, tm, bc, co, nullptr, nullptr, 0);
+        if (rc != CSP_ERR_NO_DEVICE && rc != CSP_OK) ++failures;
+        (void)csp_minsnap_last_hip_error();
+        csp_minsnap_desc bad = d;
+        bad.order = 6 + it % 3;
+        if (csp_minsnap_solve_batch(&bad, wp, tm, bc, co, nullptr, nullptr, nullptr, 0, nullptr) != CSP_ERR_UNSUPPORTED) ++failures;
+        bad = d;
+        bad.abi_version = 99;
+        if (csp_minsnap_kernel_name(&bad) != nullptr) ++failures;
+        if (csp_minsnap_solve_batch(nullptr, wp, tm, bc, co, nullptr, nullptr, nullptr, 0, nullptr) != CSP_ERR_INVALID_ARG) ++failures;
+        (void)csp_minsnap_strerror(rc);
+        // the arena pool: borrow two arenas of two "devices", hand them back, now and then drop the idle ones
+        csp::Arena *a = csp::arena_acquire(id & 1), *b = csp::arena_acquire(1 - (id & 1));
+        if (!a || !b || a == b) ++failures;
+        csp::arena_release(b);
+        csp::arena_release(a);
+        if (it % 97 == 0) csp_minsnap_release_cached_memory();
+    }
+}
+
+int main() {
+    std::vector<std::thread> th;
+    for (int i = 0; i < 8; ++i) th.emplace_back(worker, i);
+    for (auto &t : th) t.join();
+    std::printf("tsan_driver: %s (device count %d)\n", failures.load() ? "FAILED" : "ok", csp_minsnap_device_count());
+    return failures.load() ? 1 : 0;
+}

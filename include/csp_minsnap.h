@@ -15,7 +15,7 @@
  *     through the optional `status` array, never by aborting the batch;
  *   - silent: nothing is printed (the reference prints inside the solver);
  *   - thread-safe for distinct streams; no global mutable state besides the lazily built
- *     constant tables;
+ *     constant tables and the pool of staging arenas host-memory calls borrow from (mutex-protected);
  *   - the compute path is HIP on gfx950 only.  There is NO CPU fallback: without a usable
  *     device the calls return CSP_ERR_NO_DEVICE.
  *
@@ -107,7 +107,7 @@ typedef struct csp_minsnap_desc {
  *   max_dev : optional [B] f64, the reference's *max_deviation out-parameter per trajectory
  *   status  : optional [B] i32, CSP_TRAJ_* bits
  *   workspace / workspace_bytes : device scratch of at least csp_minsnap_workspace_bytes(desc)
- *             bytes (CSP_MEM_DEVICE); may be NULL/0 with CSP_MEM_HOST (allocated internally)
+ *             bytes (CSP_MEM_DEVICE); may be NULL/0 with CSP_MEM_HOST (carved from the cached arena)
  *   hip_stream : hipStream_t (NULL = default stream) */
 int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                             const void *bc, void *coeffs, double *max_dev, int32_t *status,
@@ -119,10 +119,12 @@ size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
 /* The same solve spread over `ngpu` devices of this node from ONE process (the reference planner
  * is a single C++ process).  Trajectories are independent
  * (minimum_snap.cpp has no cross-trajectory term), so the batch is cut into `ngpu` contiguous chunks
- * and chunk g runs on device g -- staging, kernel and copy-back of the chunks proceed concurrently,
- * no collective.  Host memory only (desc->mem_space must be CSP_MEM_HOST; desc->device_id is
- * ignored); synchronous.  ngpu <= 0 uses every gfx950 device; ngpu greater than the device count is
- * CSP_ERR_INVALID_ARG.  Results are identical to csp_minsnap_solve_batch on one device. */
+ * and chunk g runs on the g-th gfx950 device, each driven by a host thread of its own through that device's cached
+ * staging arena (page-locked halves, DMA overlapped with the host copy) -- staging, kernel and copy-back of the
+ * chunks proceed concurrently, no collective.  Host memory only (desc->mem_space must be CSP_MEM_HOST;
+ * desc->device_id is ignored); synchronous.  ngpu <= 0 uses every gfx950 device; ngpu greater than the device
+ * count is CSP_ERR_INVALID_ARG.  The kernel is chosen ONCE from the whole batch and pinned for the chunks, so
+ * the results are bit-identical to csp_minsnap_solve_batch on one device. */
 int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                                     const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu);
 
@@ -167,6 +169,11 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc);
 
 /* Number of visible HIP devices whose architecture is gfx950 (0 => every solve call fails). */
 int csp_minsnap_device_count(void);
+
+/* CSP_MEM_HOST calls stage through per-device arenas (one device allocation + 16 MB of page-locked memory each) that are
+ * cached between calls, so that the reference's call pattern -- one flight per call, uavPathPlanning.cpp:4423/:4461 -- does
+ * not pay hipMalloc/hipFree every time.  This frees the arenas no call is using (optional; e.g. before a long idle phase). */
+void csp_minsnap_release_cached_memory(void);
 
 const char *csp_minsnap_version(void);
 const char *csp_minsnap_strerror(int status);

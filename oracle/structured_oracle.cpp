@@ -8,7 +8,7 @@
 // shared by the three axes, per-segment Hermite -> monomial recovery.  Plain loops, OpenMP over the
 // batch.  It is NOT the oracle of record (parity is judged against dense_oracle.c and the golden
 // fixtures); tests/test_oracle.py checks it against the dense oracle so the timing line is known to
-// time a correct solve.  The tables come from oracle/minsnap_tables.py (generated header).
+// time a correct solve.  The tables come from cs-pathplan_amd/tablegen.py (generated header).
 #include "../cs-pathplan_amd/csrc/minsnap_tables.h"
 
 #include <cmath>

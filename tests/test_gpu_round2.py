@@ -198,3 +198,98 @@ def test_degenerate_segment_times_do_not_hang_the_samplers(csp, sampler):
     co2 = np.nan_to_num(plan.coeffs, nan=0.0, posinf=0.0, neginf=0.0)
     s2, n2, _ = csp.sample_batch(plan.times, co2, 0.5, 512)
     assert (n2 >= 1).all()
+
+
+def test_host_memory_calls_reuse_a_cached_arena(csp, oracle_mod):
+    """CSP_MEM_HOST calls stage through a per-device arena that survives the call (minsnap_hoststage.h): results must
+    not depend on what the arena held before -- growing, shrinking, interleaved entry points, small (one pinned copy)
+    and large (streamed through the pinned halves, > 16 MB) transfers."""
+    import torch
+    wp_big, tm_big = synth.make_batch(30000, 16, config_id=3)          # 108 MB of coefficients: streamed path
+    dev = csp.solve_batch(torch.from_numpy(wp_big).cuda(), torch.from_numpy(tm_big).cuda(), order=4).coeffs.cpu().numpy()
+    one = csp.solve_batch(wp_big[:1], tm_big[:1], order=4, want_status=True, want_max_dev=True)   # small first: arena grows later
+    assert np.array_equal(one.coeffs, dev[:1])
+    big = csp.solve_batch(wp_big, tm_big, order=4, want_status=True)
+    assert np.array_equal(big.coeffs, dev) and not big.status.any()
+    for n in (1, 7, 4096, 2, 30000, 1):                               # shrink and grow again
+        r = csp.solve_batch(wp_big[:n], tm_big[:n], order=4)
+        assert np.array_equal(r.coeffs, dev[:n]), n
+        t = csp.time_alloc_batch(wp_big[:n], 5.0, 0.1)
+        k = min(n, 16)
+        assert np.allclose(t[:k], np.stack([oracle_mod.time_alloc(w, 5.0, 0.1) for w in wp_big[:k]]), rtol=0, atol=1e-15)
+    csp.release_cached_memory()
+    r = csp.solve_batch(wp_big[:3], tm_big[:3], order=4)
+    assert np.array_equal(r.coeffs, dev[:3])
+    # the plan's host form honours per-trajectory starting weights like the device form (ADVICE r1)
+    wp, _ = synth.make_batch(40, 6, config_id=21)
+    wp4 = np.ascontiguousarray(wp * 4.0)
+    vw0 = np.linspace(0.0, 0.3, 40)
+    desc_kw = dict(order=3, path_weight=0.4)
+    import ctypes
+    def plan(host):
+        B, S, m = 40, 6, 6
+        if host:
+            times, co = np.empty((B, S)), np.empty((B, S, 3, m))
+            md, vw, it = np.empty(B), np.empty(B), np.empty(B, dtype=np.int32)
+            d = csp.make_desc(3, B, S, csp.DTYPE_F64, 0.4, 0.0, csp.MEM_HOST, False, vw_per_ptr=vw0.ctypes.data)
+            bc = np.zeros((1, 4, 3))
+            rc = csp.raw_lib().csp_minsnap_plan_batch(ctypes.byref(d), wp4.ctypes.data, 5.0, 0.1, bc.ctypes.data, times.ctypes.data,
+                                                     co.ctypes.data, md.ctypes.data, vw.ctypes.data, it.ctypes.data, None, None, 0, None)
+            assert rc == 0
+            return co, vw, it
+        t_wp, t_vw = torch.from_numpy(wp4).cuda(), torch.from_numpy(vw0).cuda()
+        times, co = torch.empty((B, S), dtype=torch.float64, device="cuda"), torch.empty((B, S, 3, m), dtype=torch.float64, device="cuda")
+        md, vw = torch.empty(B, dtype=torch.float64, device="cuda"), torch.empty(B, dtype=torch.float64, device="cuda")
+        it = torch.empty(B, dtype=torch.int32, device="cuda")
+        bc = torch.zeros((1, 4, 3), dtype=torch.float64, device="cuda")
+        d = csp.make_desc(3, B, S, csp.DTYPE_F64, 0.4, 0.0, csp.MEM_DEVICE, False, vw_per_ptr=t_vw.data_ptr(), device_id=0)
+        need = int(csp.raw_lib().csp_minsnap_plan_workspace_bytes(ctypes.byref(d)))
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        rc = csp.raw_lib().csp_minsnap_plan_batch(ctypes.byref(d), t_wp.data_ptr(), 5.0, 0.1, bc.data_ptr(), times.data_ptr(), co.data_ptr(),
+                                                 md.data_ptr(), vw.data_ptr(), it.data_ptr(), None, ws.data_ptr(), need,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        return co.cpu().numpy(), vw.cpu().numpy(), it.cpu().numpy()
+    (c_h, v_h, i_h), (c_d, v_d, i_d) = plan(True), plan(False)
+    assert np.array_equal(c_h, c_d) and np.array_equal(v_h, v_d) and np.array_equal(i_h, i_d)
+    assert i_h.max() > 0 and (v_h >= vw0).all() and len(set(np.round(v_h, 6))) > 3     # the per-trajectory starts were used
+
+
+def test_host_calls_from_several_threads(csp):
+    """Concurrent CSP_MEM_HOST calls borrow distinct arenas from the device's pool."""
+    import threading
+    wp, tm = synth.make_batch(2048, 16, config_id=3)
+    want = csp.solve_batch(wp, tm, order=4).coeffs
+    errs = []
+
+    def work(k):
+        try:
+            for i in range(6):
+                lo = (k * 97 + i * 131) % 1500
+                n = 1 + (k * 37 + i * 211) % 500
+                r = csp.solve_batch(wp[lo:lo + n], tm[lo:lo + n], order=4)
+                if not np.array_equal(r.coeffs, want[lo:lo + n]):
+                    errs.append((k, i))
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_sharded_entry_pins_the_kernel_choice(csp):
+    """An order-5 batch of 17+ segments picks the span kernel only when the WHOLE batch has >= 65536 span lanes
+    (minsnap_capi.hip use_span); the sharded entry must make that choice once for all chunks.  On this one-GPU box
+    the chunk IS the batch, so the check is that the sharded call reports / reproduces the plain call bit for bit
+    at both sides of the threshold."""
+    n = csp.device_count()
+    for B in (300, 33000):                                            # 33000 x 2 span lanes (S = 32) >= 65536: span kernel
+        wp, tm = synth.make_batch(B, 32, config_id=9)
+        a = csp.solve_batch(wp, tm, order=5)
+        b = csp.solve_batch(wp, tm, order=5, ngpu=n)
+        assert a.kernel.startswith("span_o5" if B == 33000 else "chunked_o5"), a.kernel
+        assert np.array_equal(a.coeffs, b.coeffs), B

@@ -1,10 +1,14 @@
-"""Exact-rational constant tables (oracle/minsnap_tables.py) and the scaling laws the kernels use."""
+"""Exact-rational constant tables (cs-pathplan_amd/tablegen.py) and the scaling laws the kernels use."""
 from fractions import Fraction
 
 import numpy as np
 import pytest
 
-from oracle import minsnap_tables as mt
+import importlib.util as _ilu
+import os as _os
+_spec = _ilu.spec_from_file_location("csp_tablegen", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cs-pathplan_amd", "tablegen.py"))
+mt = _ilu.module_from_spec(_spec)
+_spec.loader.exec_module(mt)
 from oracle import numpy_ref as nr
 
 
@@ -63,4 +67,4 @@ def test_header_matches_generator(tmp_path):
     import os
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     committed = open(os.path.join(here, "cs-pathplan_amd", "csrc", "minsnap_tables.h")).read()
-    assert p.read_text() == committed, "regenerate with: python oracle/minsnap_tables.py"
+    assert p.read_text() == committed, "regenerate with: python cs-pathplan_amd/tablegen.py"
