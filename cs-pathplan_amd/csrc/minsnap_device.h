@@ -24,6 +24,7 @@ template <int O> struct Tab;
         __device__ static constexpr double G(int i, int a) { return tables::G##o[i][a]; }   \
         __device__ static constexpr double QT(int a, int b) { return tables::QT##o[a][b]; } \
         __device__ static constexpr double HW(int s, int a) { return tables::HW##o[s][a]; } \
+        __device__ static constexpr double KQ(int t, int i) { return tables::KQ##o[t][i]; } \
     };
 CSP_TAB(1) CSP_TAB(2) CSP_TAB(3) CSP_TAB(4) CSP_TAB(5)
 #undef CSP_TAB

@@ -246,31 +246,70 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
         for (int ax = 0; ax < 3; ++ax) { P0[ax] = in.P(j, ax); P1[ax] = in.P(j + 1, ax); }
         if (!PEN) {
             // pass A: where does the pre-solve polynomial stray farthest from the chord?  Samples in
-            // GLOBAL order 0..16 (the bottom role's frame is reversed), first maximum wins.
-            double dh[3][M];  // scaled endpoint derivatives of the local frame
+            // GLOBAL order 0..16 (the bottom role's frame is reversed), first maximum wins (strict >, :435).
+            // The deviation e(sigma) = P(sigma) - L(sigma) vanishes at both waypoints, so per axis
+            //   e(sigma) = sigma (1 - sigma) q(u),  u = sigma - 1/2,  q of degree 2o-3 (table KQ, tablegen.py),
+            // and d2(s) = (sigma (1 - sigma))^2 |q(u_s)|^2.  Samples s and 16 - s are +-u: q(+-u) = E(u^2) +- u O(u^2),
+            // one even/odd Horner pass for both; samples 0 and 16 are exactly 0 (the reference's are rounding noise
+            // there: its search starts from sample 0 as well and never ends on sample 16).
+            constexpr int NQ = M - 2;   // coefficients of q
+            double cq[3][NQ];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                dh[ax][0] = P0[ax];
-                dh[ax][O] = P1[ax];
+                const double dp = P1[ax] - P0[ax];
+                double hs[N], he[N];
 #pragma unroll
-                for (int r = 0; r < N; ++r) { dh[ax][r + 1] = xk[r][ax] * tp[r]; dh[ax][O + r + 1] = xn[r][ax] * tp[r]; }
+                for (int r = 0; r < N; ++r) { hs[r] = xk[r][ax] * tp[r]; he[r] = xn[r][ax] * tp[r]; }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    double v = Tab<O>::KQ(0, i) * dp;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        v = __builtin_fma(Tab<O>::KQ(1 + r, i), hs[r], v);
+                        v = __builtin_fma(Tab<O>::KQ(1 + N + r, i), he[r], v);
+                    }
+                    cq[ax][i] = v;
+                }
             }
-            double best = -1.0;
-            int best_s = 0;
-#pragma unroll
-            for (int sg = 0; sg <= 16; ++sg) {
-                const int sl = BOTTOM ? 16 - sg : sg;  // local sample index
-                double d2 = 0.0;
+            // Strict '>' scan in GLOBAL sample order 0..16 = the first maximum.  Sample 0 is the starting value (d2 = 0);
+            // a pair (u = -+p/16) yields global samples 8-p and 8+p.  The low samples arrive in scan order (p = 7..1:
+            // globals 1..7) and take a strict '>'; the high ones arrive in REVERSE scan order (globals 15..9), where '>='
+            // keeps the smallest index among equals; the two halves and the middle sample are then combined in scan
+            // order.  A rolled loop on purpose: unrolled, the seven pairs' temporaries compete with the stored factors
+            // (most of the register file) and the kernel spills.
+            double best_lo = 0.0, best_hi = -1.0;
+            int g_lo = 0, g_hi = 16;                  // global sample indices
+#pragma unroll 1
+            for (int p_ = 7; p_ >= 1; --p_) {
+                const double u = (double)p_ * 0.0625, u2 = u * u;
+                const double hw = 0.25 - u2, wgt = hw * hw;
+                double sp = 0.0, sm = 0.0;
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
-                    double v = 0.0;
+                    // even part: coefficients 0, 2, ..; odd part: 1, 3, ..  (NQ is even: NQ/2 of each)
+                    double ev = cq[ax][NQ - 2], od = cq[ax][NQ - 1];
 #pragma unroll
-                    for (int q = 0; q < M; ++q) v = __builtin_fma(Tab<O>::HW(sl, q), dh[ax][q], v);
-                    const double Lc = __builtin_fma((double)sl * 0.0625, P1[ax] - P0[ax], P0[ax]);
-                    d2 = __builtin_fma(v - Lc, v - Lc, d2);
+                    for (int i = NQ - 4; i >= 0; i -= 2) {
+                        ev = __builtin_fma(ev, u2, cq[ax][i]);
+                        od = __builtin_fma(od, u2, cq[ax][i + 1]);
+                    }
+                    const double qp = __builtin_fma(od, u, ev), qm = __builtin_fma(-od, u, ev);
+                    sp = __builtin_fma(qp, qp, sp);
+                    sm = __builtin_fma(qm, qm, sm);
                 }
-                if (d2 > best) { best = d2; best_s = sl; }
+                // local samples 8 - p (u < 0: sm) and 8 + p (u > 0: sp); global index = local (top role) or 16 - local (bottom)
+                const double lo = wgt * (BOTTOM ? sp : sm), hi = wgt * (BOTTOM ? sm : sp);
+                if (lo > best_lo) { best_lo = lo; g_lo = 8 - p_; }
+                if (hi >= best_hi) { best_hi = hi; g_hi = 8 + p_; }
             }
+            double best = best_lo;
+            int best_g = g_lo;
+            {
+                const double mid = 0.0625 * __builtin_fma(cq[2][0], cq[2][0], __builtin_fma(cq[1][0], cq[1][0], cq[0][0] * cq[0][0]));
+                if (mid > best) { best = mid; best_g = 8; }
+            }
+            if (best_hi > best) { best = best_hi; best_g = g_hi; }
+            const int best_s = BOTTOM ? 16 - best_g : best_g;   // local sample index
             tau[j] = best_s;
         } else {
             const int g = BOTTOM ? S - 1 - j : j;
@@ -310,8 +349,24 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 len2 = __builtin_fma(dp, dp, len2);
             }
             {
-                const double seg_len = sqrt(len2);
-                const double ratio = (seg_len > 1e-6) ? sqrt(d2) / seg_len : 0.0;
+                // deviation / chord length (:612-616: chords of <= 1e-6 are skipped).
+                // Order 2: `maxdev` carries the SQUARED ratio (one square root per trajectory, in path_role: two square
+                // roots and a division per segment were a fifth of this short sweep), branch-free, so that the 8
+                // unrolled segments of a half form ONE scheduling region -- registers are plentiful at order 2 and
+                // the interleaving hides the fp64 latencies of a lone wave (46.8 us against 54.2 with a branch).
+                // Orders 3-4: the ratio itself, as one square root of the ratio of squares, inside a REAL branch
+                // (the empty asm keeps it one): it ends the basic block once per segment.  As one block the segments
+                // are register-allocated together and, with the stored factors filling most of the file, end in
+                // scratch (1.4 KB/lane at order 4, S = 16: 170 us instead of 98).
+                double ratio = 0.0;
+                if constexpr (O == 2) {
+                    ratio = (len2 > 1e-12) ? d2 * fast_rcp(len2) : 0.0;
+                } else {
+                    if (len2 > 1e-12) {
+                        asm volatile("" ::: "memory");
+                        ratio = sqrt(d2 * fast_rcp(len2));
+                    }
+                }
                 maxdev = ratio > maxdev ? ratio : maxdev;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -374,7 +429,7 @@ __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int 
     lds_barrier();
     const bool live = lane < rows && !l_skip[lane];
     if (!BOTTOM && live) {
-        if (a.max_dev) a.max_dev[b] = fmax(maxdev, l_dev[lane]);
+        if (a.max_dev) a.max_dev[b] = O == 2 ? sqrt(fmax(maxdev, l_dev[lane])) : fmax(maxdev, l_dev[lane]);
         if (STATUS) a.status[b] = bits | l_bits[lane];
     }
 }

@@ -120,6 +120,48 @@ def hermite_sample_weights(o):
     return out
 
 
+def _polydiv_exact(num, den):
+    """Polynomials as ascending coefficient lists of Fractions; returns the quotient, asserts a zero remainder."""
+    num = list(num)
+    q = [Fraction(0)] * (len(num) - len(den) + 1)
+    for k in range(len(q) - 1, -1, -1):
+        q[k] = num[k + len(den) - 1] / den[-1]
+        for j, d in enumerate(den):
+            num[k + j] -= q[k] * d
+    assert all(v == 0 for v in num), "not divisible"
+    return q
+
+
+def deviation_quotient(o):
+    """KQ[t][i] (t = 0..2o-2, i = 0..2o-3) for the path penalty's 17-sample search (minimum_snap.cpp:408-439).
+
+    In normalised time sigma = t/T the pre-solve polynomial of a segment minus its chord L = P0 + sigma*dP is
+        e(sigma) = (H_endpos(sigma) - sigma) dP + sum_r H_start,r(sigma) dh_s[r] + H_end,r(sigma) dh_e[r]
+    (dh = endpoint derivatives scaled by T^deriv; H_startpos + H_endpos = 1).  Every one of those 2o-1 basis
+    functions vanishes at sigma = 0 and 1, so e(sigma) = sigma (1 - sigma) q(sigma) with q of degree 2o-3.
+    KQ[t] holds basis function t's quotient in powers of u = sigma - 1/2 (t = 0: the dP term, 1..o-1: start
+    derivatives, o..2o-2: end derivatives): the samples s and 16-s are u and -u, so one even/odd Horner pass
+    serves both.  Exact rationals."""
+    if o < 2:
+        return [[Fraction(0)]]
+    G, _ = tables(o)
+    m = 2 * o
+    den = [Fraction(0), Fraction(1), Fraction(-1)]          # sigma - sigma^2
+    out = []
+    for a in [o] + list(range(1, o)) + list(range(o + 1, m)):
+        h = [G[m - 1 - k][a] for k in range(m)]                # ascending powers of sigma
+        if a == o:
+            h[1] -= 1
+        q = _polydiv_exact(h, den)                             # degree 2o-3, ascending in sigma
+        # re-centre: sigma = u + 1/2
+        c = [Fraction(0)] * len(q)
+        for k, qk in enumerate(q):
+            for i in range(k + 1):
+                c[i] += qk * math.comb(k, i) * Fraction(1, 2) ** (k - i)
+        out.append(c)
+    return out
+
+
 def tables_float(o):
     G, Qt1 = tables(o)
     return ([[float(v) for v in r] for r in G], [[float(v) for v in r] for r in Qt1])
@@ -161,6 +203,13 @@ def emit_header(path):
         lines.append("// HW<o>[s][a] = Hermite basis function of endpoint derivative a at t/T = s/16 (path-penalty samples)")
         lines.append("CSP_TABLE_QUAL double HW%d[17][%d] = {" % (o, m))
         for r in hermite_sample_weights(o):
+            lines.append("  {" + ", ".join(_c_double(v) for v in r) + "},")
+        lines.append("};")
+        kq = deviation_quotient(o)
+        lines.append("// KQ<o>[t][i]: (pre-solve polynomial - chord)(sigma) = sigma (1 - sigma) * sum_t term_t * sum_i KQ[t][i] (sigma - 1/2)^i,")
+        lines.append("// terms: dP, scaled start derivatives 1..o-1, scaled end derivatives 1..o-1 (tablegen.py deviation_quotient)")
+        lines.append("CSP_TABLE_QUAL double KQ%d[%d][%d] = {" % (o, len(kq), len(kq[0])))
+        for r in kq:
             lines.append("  {" + ", ".join(_c_double(v) for v in r) + "},")
         lines.append("};")
         lines.append("")

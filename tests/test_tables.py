@@ -68,3 +68,25 @@ def test_header_matches_generator(tmp_path):
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     committed = open(os.path.join(here, "cs-pathplan_amd", "csrc", "minsnap_tables.h")).read()
     assert p.read_text() == committed, "regenerate with: python cs-pathplan_amd/tablegen.py"
+
+
+@pytest.mark.parametrize("o", [2, 3, 4, 5])
+def test_deviation_quotient_reproduces_the_hermite_samples(o):
+    """KQ (tablegen.deviation_quotient): P(sigma) - L(sigma) = sigma (1 - sigma) q(sigma - 1/2) at the 17 samples of the
+    path penalty's search (minimum_snap.cpp:408-439) -- exactly, in rational arithmetic, against the Hermite weights HW
+    the generic kernel and the oracle-facing tests use."""
+    import random
+    random.seed(o)
+    HW = mt.hermite_sample_weights(o)
+    KQ = mt.deviation_quotient(o)
+    m = 2 * o
+    assert len(KQ) == m - 1 and all(len(r) == m - 2 for r in KQ)
+    d = [Fraction(random.randint(-50, 50), random.randint(1, 9)) for _ in range(m)]   # scaled endpoint derivatives [start.., end..]
+    P0, P1 = d[0], d[o]
+    terms = [P1 - P0] + [d[1 + r] for r in range(o - 1)] + [d[o + 1 + r] for r in range(o - 1)]
+    for s_ in range(17):
+        sigma = Fraction(s_, 16)
+        direct = sum(HW[s_][a] * d[a] for a in range(m)) - (P0 + sigma * (P1 - P0))
+        u = sigma - Fraction(1, 2)
+        q = sum(terms[t] * sum(KQ[t][i] * u ** i for i in range(m - 2)) for t in range(m - 1))
+        assert direct == sigma * (1 - sigma) * q, (o, s_)

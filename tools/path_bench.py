@@ -1,37 +1,23 @@
-"""Times the path-penalty solve: register-resident kernel vs generic kernel.
-    python tools/path_bench.py [B]            (GPU box; prints one JSON line per configuration)"""
+"""Path-penalty kernel (row A7 / the shipped yaml's configuration) at B = 65536: us per launch and fraction of the HBM
+roofline by algorithmic bytes, per order and segment count; `--plan` adds the whole re-solve loop (csp_minsnap_plan_batch).
+    python tools/path_bench.py [--plan]"""
+import importlib
 import json
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, ".")
-import importlib
-csp = importlib.import_module("cs-pathplan_amd")
+import bench
 from tests import synth
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for order, S in ((4, 16), (4, 8), (3, 16), (2, 16)):
-    wp, tm = synth.make_batch(B, S, config_id=7)
-    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
-    row = {"order": order, "S": S, "B": B, "bytes_per_solve": synth.algorithmic_bytes(S, order)}
-    outs = {}
-    for name, force in (("fixedpath", False), ("generic", True)):
-        ps = csp.PreparedSolve(d_wp, d_tm, order=order, path_weight=0.1, vel_zero_weight=0.01, force_generic=force)
-        for _ in range(3):
-            ps.run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 20
-        e0.record()
-        for _ in range(n):
-            ps.run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / n
-        outs[name] = ps.out.cpu().numpy().copy()
-        row[name] = {"kernel": ps.kernel, "us": round(us, 1), "solves_per_s": round(B / us * 1e6, 0),
-                     "algorithmic_GBps": round(B * row["bytes_per_solve"] / us * 1e-3, 1)}
-    row["rel_err_fixed_vs_generic"] = float(synth.rel_err(outs["fixedpath"], outs["generic"]))
-    print(json.dumps(row), flush=True)
+csp = importlib.import_module("cs-pathplan_amd")
+dev = torch.device("cuda", 0)
+for (o, S, pw, vw) in ((2, 16, 1e-7, 0.01), (3, 16, 1e-7, 0.01), (4, 16, 1e-7, 0.01), (4, 8, 0.1, 0.01), (2, 6, 1e-7, 0.01)):
+    rec, prep, wp, tm = bench.bench_uniform(csp, dev, 65536, S, o, 20, 3, 3, pw=pw, vw=vw)
+    print(json.dumps({"order": o, "S": S, "kernel": rec["kernel"], "us": round(rec["kernel_ms"] * 1e3, 1),
+                      "solves_per_s": "%.3g" % rec["solves_per_s"], "frac_hbm": round(rec["frac_of_hbm_peak"], 3)}), flush=True)
+    if "--plan" in sys.argv:
+        d_wp = torch.from_numpy(wp * 4.0).to(dev)
+        ms = bench.timed(lambda: csp.plan_batch(d_wp, 5.0, 0.1, order=o, path_weight=0.3), 5, 2, dev)
+        print(json.dumps({"order": o, "S": S, "plan_batch_ms_all_passes": round(ms, 3)}), flush=True)
