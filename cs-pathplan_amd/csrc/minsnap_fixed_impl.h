@@ -224,6 +224,10 @@ template <bool BOTTOM> struct RoleBc {
         vw = a.vw_per ? a.vw_per[b] : a.vel_zero_weight;
     }
     __device__ __forceinline__ double at(int r, int ax) const { return r == 0 ? v[ax] : r == 1 ? acc[ax] : 0.0; }
+    // the same for an axis index that differs between lanes (selects instead of a dynamically indexed register array)
+    __device__ __forceinline__ double at_sel(int r, int ax) const {
+        return r == 0 ? (ax == 0 ? v[0] : ax == 1 ? v[1] : v[2]) : r == 1 ? (ax == 0 ? acc[0] : ax == 1 ? acc[1] : acc[2]) : 0.0;
+    }
     // batch-wide values are wave-uniform: park them in scalar registers for the life of the slice loop
     __device__ __forceinline__ void to_sgpr() {
         auto u = [](double x) {
@@ -237,36 +241,41 @@ template <bool BOTTOM> struct RoleBc {
     }
 };
 
-template <int O, int S, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook>
+// NAX = 3: one lane per trajectory (all three axes).  NAX = 1 (small batches, see launch_s): THREE lanes per trajectory,
+// lane = (axis ax0, staging row `row`), each factorising redundantly and carrying one right-hand side -- about half the
+// instructions per lane, which is what a lone latency-bound wave is made of.
+template <int O, int S, bool BOTTOM, bool STATUS, bool FULL, bool SEGMAJ, bool STASH, class In, class Hook, int NAX = 3>
 __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int64_t b, int lane,
                                            const In &in, const RoleBc<BOTTOM> &rbc, double *stage, double *partner_stage,
-                                           double *tst, const Hook &after_exchange, int rows = 64) {
+                                           double *tst, const Hook &after_exchange, int rows = 64, int row_ = 0, int ax0 = 0) {
+    static_assert(NAX == 3 || (NAX == 1 && !FULL && !STASH), "the axis-per-lane mapping serves the narrow one-slice kernel only");
+    const int row = NAX == 3 ? lane : row_;   // staging-tile row = trajectory within the slice
     constexpr int N = O - 1, M = 2 * O;
     constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;   // segments of THIS role; both roles meet at waypoint ceil(S/2)
     using L = FixedLds<O, S>;
     auto Tl = [&](int j) { return in.T(j); };
-    auto Pl = [&](int j, int ax) { return in.P(j, ax); };
+    auto Pl = [&](int j, int ax) { return in.P(j, ax0 + ax); };
     const double vw = rbc.vw;
-    auto bc_at = [&](int r, int ax) { return rbc.at(r, ax); };
+    auto bc_at = [&](int r, int ax) { return NAX == 3 ? rbc.at(r, ax) : rbc.at_sel(r, ax0 + ax); };
 
-    double z[N][3], W[N][N];
+    double z[N][NAX], W[N][N];
 #pragma unroll
     for (int r = 0; r < N; ++r) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) z[r][ax] = bc_at(r, ax);
+        for (int ax = 0; ax < NAX; ++ax) z[r][ax] = bc_at(r, ax);
 #pragma unroll
         for (int c = 0; c < N; ++c) W[r][c] = 0.0;
     }
-    double Wst[HS][N][N], zst[HS][N][3];  // slot k = local waypoint k (slot 0 unused)
+    double Wst[HS][N][N], zst[HS][N][NAX];  // slot k = local waypoint k (slot 0 unused)
     bool spd = true;
 
     // ---- forward elimination over local interior waypoints 1..HS-1 ----
     Seg<O> left, right;
-    double Pst[HS + 1][3];  // STASH only (the segment times are stashed in LDS: tst[j*64 + lane])
+    double Pst[HS + 1][NAX];  // STASH only (the segment times are stashed in LDS: tst[j*64 + lane])
     { const double t0 = Tl(0); if (STASH) tst[lane] = t0; seg_make<O>(t0, vw, left); }
-    double Pa[3], Pb[3], Pc[3];  // local waypoints k-1, k, k+1
+    double Pa[NAX], Pb[NAX], Pc[NAX];  // local waypoints k-1, k, k+1
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
+    for (int ax = 0; ax < NAX; ++ax) {
         Pa[ax] = Pl(0, ax);
         Pb[ax] = Pl(1, ax);
         if (STASH) { Pst[0][ax] = Pa[ax]; Pst[1][ax] = Pb[ax]; }
@@ -275,8 +284,8 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     for (int k = 1; k < HS; ++k) {
         { const double tk = Tl(k); if (STASH) tst[k * 64 + lane] = tk; seg_make<O>(tk, vw, right); }
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { Pc[ax] = Pl(k + 1, ax); if (STASH) Pst[k + 1][ax] = Pc[ax]; }
-        double Sm[N][N], R[N][N + 3];  // right-hand sides: [C_k | y_k]
+        for (int ax = 0; ax < NAX; ++ax) { Pc[ax] = Pl(k + 1, ax); if (STASH) Pst[k + 1][ax] = Pc[ax]; }
+        double Sm[N][N], R[N][N + NAX];  // right-hand sides: [C_k | y_k]
 #pragma unroll
         for (int r = 0; r < N; ++r) {
 #pragma unroll
@@ -289,7 +298,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
             for (int c = 0; c < N; ++c) R[r][c] = right.se[r][c];
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 double v = left.ep[r] * (Pb[ax] - Pa[ax]);
                 v = __builtin_fma(right.sp[r], Pc[ax] - Pb[ax], v);
 #pragma unroll
@@ -297,22 +306,22 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 R[r][N + ax] = v;
             }
         }
-        spd &= SmallSpd<N, N + 3>::solve(Sm, R);
+        spd &= SmallSpd<N, N + NAX>::solve(Sm, R);
 #pragma unroll
         for (int r = 0; r < N; ++r) {
 #pragma unroll
             for (int c = 0; c < N; ++c) { W[r][c] = R[r][c]; Wst[k][r][c] = R[r][c]; }
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) { z[r][ax] = R[r][N + ax]; zst[k][r][ax] = R[r][N + ax]; }
+            for (int ax = 0; ax < NAX; ++ax) { z[r][ax] = R[r][N + ax]; zst[k][r][ax] = R[r][N + ax]; }
         }
         left = right;
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
+        for (int ax = 0; ax < NAX; ++ax) { Pa[ax] = Pb[ax]; Pb[ax] = Pc[ax]; }
     }
 
     CSP_STAMP(2);
     // ---- Schur carry of this half onto the middle waypoint, exchanged through LDS ----
-    double Cm[N][N], cm[N][3];
+    double Cm[N][N], cm[N][NAX];
 #pragma unroll
     for (int r = 0; r < N; ++r) {
 #pragma unroll
@@ -323,7 +332,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
             Cm[r][c] = v;
         }
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
+        for (int ax = 0; ax < NAX; ++ax) {
             double v = left.ep[r] * (Pb[ax] - Pa[ax]);
 #pragma unroll
             for (int j = 0; j < N; ++j) v = __builtin_fma(-left.se[j][r], z[j][ax], v);
@@ -340,15 +349,15 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) mine[(e++) * 64 + lane] = cm[r][ax];
+            for (int ax = 0; ax < NAX; ++ax) mine[(e++) * 64 + lane] = cm[r][ax];
     }
     lds_barrier();
     after_exchange();
     CSP_STAMP(3);
-    double xm[N][3];
+    double xm[N][NAX];
     {
         const double *other = stage;
-        double Sm[N][N], R[N][3];
+        double Sm[N][N], R[N][NAX];
         int e = 0;
 #pragma unroll
         for (int r = 0; r < N; ++r)
@@ -360,15 +369,15 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 const double o = other[(e++) * 64 + lane];
                 R[r][ax] = cm[r][ax] + ((r & 1) ? o : -o);  // derivative r+1 is odd for even r
             }
-        spd &= SmallSpd<N, 3>::solve(Sm, R);
+        spd &= SmallSpd<N, NAX>::solve(Sm, R);
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) xm[r][ax] = R[r][ax];
+            for (int ax = 0; ax < NAX; ++ax) xm[r][ax] = R[r][ax];
     }
 
     // ---- back-substitution fused with coefficient recovery, local segments HS-1 .. 0 ----
@@ -393,18 +402,18 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     const unsigned o8 = (unsigned)((lane >> 3) * RS + (lane & 7) * 16);
     const int l16 = (lane >> 4) * ROW + (lane & 15) * 2;         // 16 lanes per 256-byte run, tile doubles 0..31
     const unsigned o16 = (unsigned)((lane >> 4) * RS + (lane & 15) * 16);
-    double xn[N][3];  // free derivatives at local waypoint j+1
+    double xn[N][NAX];  // free derivatives at local waypoint j+1
 #pragma unroll
     for (int r = 0; r < N; ++r)
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xm[r][ax];
+        for (int ax = 0; ax < NAX; ++ax) xn[r][ax] = xm[r][ax];
 #pragma unroll
     for (int j = HS - 1; j >= 0; --j) {
-        double xk[N][3];  // free derivatives at local waypoint j
+        double xk[N][NAX];  // free derivatives at local waypoint j
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 if (j == 0) {
                     xk[r][ax] = bc_at(r, ax);
                 } else {
@@ -428,7 +437,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         const bool paired = PAIRING && !((HS & 1) && g == (BOTTOM ? HS : HS - 1));
         const bool first = BOTTOM ? (g & 1) == 0 : (g & 1) == 1;  // first record of its pair to reach this wave
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
+        for (int ax = 0; ax < NAX; ++ax) {
             double xs[N], xe[N], c[M];
             // global orientation: the bottom role's local start is the global END, and odd
             // derivatives change sign back
@@ -444,7 +453,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
             recover<O>(Ps, Pe - Ps, xs, xe, tp, ip, c);
             // lane-major staging tile (row = lane); where the axis block lands depends on the
             // record's place in its pair (order 4 only, see below)
-            const int tpos = !paired ? ax * M
+            const int tpos = !paired ? (ax0 + ax) * M
                            : (!BOTTOM ? (first ? (ax == 0 ? 24 : ax * M) : ax * M)
                                       : (first ? (ax == 2 ? 0 : 8 + ax * M) : 8 + ax * M));
 #pragma unroll
@@ -452,7 +461,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 double2 v2;
                 v2.x = c[i];
                 v2.y = c[i + 1];
-                *reinterpret_cast<double2 *>(stage + lane * ROW + tpos + i) = v2;
+                *reinterpret_cast<double2 *>(stage + row * ROW + tpos + i) = v2;
             }
             if (STATUS) {
 #pragma unroll
@@ -502,10 +511,12 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                             *reinterpret_cast<const double2 *>(stage + lds_off + NFULL * L::RPI * ROW);
                 }
             } else {
+                // the axis-per-lane mapping serves slices of <= 16 rows: only the first stores can hold one
+                constexpr int NI_USED = NAX == 3 ? L::NI : (16 + L::RPI - 1) / L::RPI;
 #pragma unroll
-                for (int i = 0; i < L::NI; ++i) {
-                    const int row = i * L::RPI + grp;
-                    if (lane < L::RPI * L::LPR && row < rows) {
+                for (int i = 0; i < NI_USED; ++i) {
+                    const int srow = i * L::RPI + grp;
+                    if (lane < L::RPI * L::LPR && srow < rows) {
                         const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
                         *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v2;
                     }
@@ -516,11 +527,11 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) xn[r][ax] = xk[r][ax];
+            for (int ax = 0; ax < NAX; ++ax) xn[r][ax] = xk[r][ax];
     }
     CSP_STAMP(4);
     CSP_STAMP_RT(6);
-    if (STATUS && lane < rows) {
+    if (STATUS && row < rows) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
     }
@@ -528,7 +539,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 
 // FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
 // batch is a second, single-workgroup launch of the FULL=false variant.
-template <int O, int S, bool STATUS, bool FULL, bool SEGMAJ>
+template <int O, int S, bool STATUS, bool FULL, bool SEGMAJ, int NAX = 3>
 __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     using L = FixedLds<O, S>;
     __shared__ __attribute__((aligned(16))) double lds[L::TOTAL_DOUBLES];
@@ -575,18 +586,24 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     __syncthreads();
     CSP_STAMP(1);
 
-    int64_t b = b0 + lane;
+    // NAX = 1 (slices of <= 16 trajectories): lane = (axis, row); the lanes beyond 3 * slice_w repeat axis 2 (same values
+    // into the same staging cells)
+    const int row = NAX == 3 ? lane : (lane & (slice_w - 1));
+    const int ax0 = NAX == 3 ? 0 : ((lane / slice_w) < 2 ? (lane / slice_w) : 2);
+    int64_t b = b0 + row;
     if (b >= a.B) b = a.B - 1;  // idle lanes of a ragged last workgroup: harmless, store nothing
     if (role == 0) {
-        const LdsInputs<S, false> in{l_wp, l_tm, lane};
+        const LdsInputs<S, false> in{l_wp, l_tm, row};
         RoleBc<false> rbc;
         rbc.load(a, b);
-        fixed_body<O, S, false, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{}, rows);
+        fixed_body<O, S, false, STATUS, FULL, SEGMAJ, false, LdsInputs<S, false>, NoHook, NAX>(
+            a, b0, b, lane, in, rbc, l_stage, l_stage + L::STAGE_DOUBLES, nullptr, NoHook{}, rows, row, ax0);
     } else {
-        const LdsInputs<S, true> in{l_wp, l_tm, lane};
+        const LdsInputs<S, true> in{l_wp, l_tm, row};
         RoleBc<true> rbc;
         rbc.load(a, b);
-        fixed_body<O, S, true, STATUS, FULL, SEGMAJ, false>(a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{}, rows);
+        fixed_body<O, S, true, STATUS, FULL, SEGMAJ, false, LdsInputs<S, true>, NoHook, NAX>(
+            a, b0, b, lane, in, rbc, l_stage + L::STAGE_DOUBLES, l_stage, nullptr, NoHook{}, rows, row, ax0);
     }
 }
 
@@ -701,29 +718,39 @@ __global__ void __launch_bounds__(128) minsnap_fixed_persistent_kernel(GenericAr
 }
 
 // ---- host side: launch one order's kernels -----------------------------------------------------
-// Trajectories per workgroup for the one-workgroup-per-slice kernel: halve from 64 while the batch would leave CUs
-// without a workgroup (two per CU fit), not below 8.  CSP_SLICE_W overrides (tuning experiments).
-inline int narrow_slice(int64_t B, int cus) {
+// Trajectories per workgroup for the one-workgroup-per-slice kernel.  A small batch is latency-bound -- a lone wave's
+// instruction stream is the run time -- so what helps is fewer instructions per lane, not more workgroups: with the
+// three-lanes-per-trajectory mapping (order 4) batches of B <= 32 * CUs trajectories run as
+// slices of 16 (measured, B = 4096, S = 8: 8.2 us one lane per trajectory in slices of 64, 7.9 us in slices of 16,
+// 6.1 us with three lanes per trajectory; B = 8192: 9.3 -> 8.8 us).  Everything else keeps 64.  CSP_SLICE_W overrides
+// (tuning experiments: 8, 16, 32, 64).
+inline int narrow_slice(int64_t B, int cus, bool axis_lanes) {
     static const int forced = [] { const char *e = std::getenv("CSP_SLICE_W"); return e ? std::atoi(e) : 0; }();
     if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;   // even: 16-byte pieces stay aligned
-    static const int per_cu = [] { const char *e = std::getenv("CSP_SLICE_PER_CU"); return e ? std::atoi(e) : 1; }();
-    int w = 64;
-    while (w > 8 && (B + w - 1) / w < (per_cu > 0 ? per_cu : 1) * (int64_t)cus) w >>= 1;
-    return w;
+    return (axis_lanes && B <= 32 * (int64_t)cus) ? 16 : 64;
+}
+inline bool axis_lanes_enabled() {   // CSP_AXIS_LANES=0 switches the three-lanes-per-trajectory mapping off (A/B runs)
+    static const bool on = [] { const char *e = std::getenv("CSP_AXIS_LANES"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
-// SEGMAJ_OK: whether the segment-major layout is instantiated for this order (order 4 only).
 template <int O, int S, bool SEGMAJ_OK>
 hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
     const dim3 block(128);
-    // A small batch (fewer 64-trajectory slices than two workgroups per CU) is latency-bound, and what a workgroup
-    // moves through ONE CU's memory path is on that latency: cut it into narrower slices so that every CU gets a
-    // workgroup (C2: B = 4096 -> 512 workgroups of 8 instead of 64 of 64).
-    const int w = narrow_slice(a.B, cus);
+    const bool axis_ok = O == 4 && !a.seg_major && axis_lanes_enabled();
+    const int w = narrow_slice(a.B, cus, axis_ok);
     if (w < 64 && !a.seg_major) {
         GenericArgs t = a;
         t.slice_w = w;
         const dim3 grid((unsigned)((a.B + w - 1) / w));
+        if constexpr (O == 4) {
+            // slices of <= 16 trajectories: three lanes per trajectory, one per axis (fixed_body NAX = 1)
+            if (w <= 16 && axis_ok) {
+                if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false, 1>), grid, block, 0, st, t);
+                else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false, 1>), grid, block, 0, st, t);
+                return hipGetLastError();
+            }
+        }
         if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false>), grid, block, 0, st, t);
         else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false>), grid, block, 0, st, t);
         return hipGetLastError();

@@ -293,3 +293,38 @@ def test_sharded_entry_pins_the_kernel_choice(csp):
         b = csp.solve_batch(wp, tm, order=5, ngpu=n)
         assert a.kernel.startswith("span_o5" if B == 33000 else "chunked_o5"), a.kernel
         assert np.array_equal(a.coeffs, b.coeffs), B
+
+
+@pytest.mark.parametrize("S", [2, 3, 8, 15, 16])
+def test_axis_per_lane_mapping_of_small_batches(csp, oracle_mod, S):
+    """Order-4 batches of up to 32 x CUs trajectories run in slices of 16 with THREE lanes per trajectory (one axis each,
+    minsnap_fixed_impl.h NAX = 1).  Same arithmetic per axis as the one-lane-per-trajectory kernels: the small batch must
+    equal, bit for bit, the same trajectories solved inside a large batch (persistent kernel), for ragged slice tails,
+    per-trajectory boundary conditions and weights; plus the oracle and the status flags."""
+    import torch
+    rng = np.random.default_rng(S)
+    big_B = 40000
+    wp, tm = synth.make_batch(big_B, S, config_id=2)
+    bc = rng.normal(size=(big_B, 4, 3))
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    big = csp.solve_batch(d_wp, d_tm, order=4).coeffs
+    for B in (1, 5, 16, 17, 100, 4096):
+        r = csp.solve_batch(d_wp[:B].contiguous(), d_tm[:B].contiguous(), order=4, want_status=True)
+        assert r.kernel == "fixed_o4_s%d_f64" % S
+        assert torch.equal(r.coeffs, big[:B]), (S, B)
+        assert int(r.status.abs().max()) == 0
+    B = 333
+    vw = rng.uniform(0.0, 0.3, size=B)
+    a = csp.solve_batch(wp[:B], tm[:B], bc[:B], order=4, vel_zero_weight_per_traj=vw, want_status=True)
+    g = csp.solve_batch(wp[:B], tm[:B], bc[:B], order=4, vel_zero_weight_per_traj=vw, force_generic=True)
+    assert synth.rel_err_per_power(a.coeffs, g.coeffs) < 1e-9 and not a.status.any()
+    ref, _ = oracle_mod.solve_batch(4, wp[:64], tm[:64], bc[:64], vel_zero_weight=0.0, nthreads=oracle_mod.max_threads())
+    r0 = csp.solve_batch(wp[:64], tm[:64], bc[:64], order=4)
+    assert synth.rel_err_per_power(r0.coeffs, ref) < NORTH_STAR_TOL
+    bad = tm[:40].copy()
+    bad[7, :] = -bad[7, :]          # every block negative definite: not SPD
+    bad[21, 0] = float("nan")
+    rb = csp.solve_batch(wp[:40], bad, order=4, want_status=True)
+    assert np.flatnonzero(rb.status).tolist() == [7, 21], rb.status
+    ok = np.setdiff1d(np.arange(40), [7, 21])
+    assert np.array_equal(rb.coeffs[ok], big[:40].cpu().numpy()[ok])
