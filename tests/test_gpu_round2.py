@@ -328,3 +328,65 @@ def test_axis_per_lane_mapping_of_small_batches(csp, oracle_mod, S):
     assert np.flatnonzero(rb.status).tolist() == [7, 21], rb.status
     ok = np.setdiff1d(np.arange(40), [7, 21])
     assert np.array_equal(rb.coeffs[ok], big[:40].cpu().numpy()[ok])
+
+
+def test_c5_full_size_mixed_batch(csp, oracle_mod):
+    """BASELINE C5 at the size bench.py times: B = 65536 mixed trajectories (S ~ U{4..64}, order ~ U{3,4,5}), fp32 storage /
+    fp64 arithmetic, bucketed by order and length class (cs-pathplan_amd/mixed.py::MixedBatch, nine ragged launches).
+    Size-independent properties on every trajectory of every bucket (interpolation of the waypoints at both segment ends,
+    continuity of velocity and acceleration at interior waypoints, zero boundary velocity / acceleration -- all to fp32
+    resolution) and 192 trajectories spread over the batch against the 80-bit oracle on the fp32-rounded inputs."""
+    import importlib.util, os
+    import torch
+    spec = importlib.util.spec_from_file_location("csp_mixed", os.path.join(os.path.dirname(csp.__file__), "mixed.py"))
+    mixed = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mixed)
+    B = 65536
+    trajs = synth.make_ragged(B)
+    mb = mixed.MixedBatch(csp, trajs, torch.device("cuda", 0), dtype=torch.float32)
+    assert mb.launches == 9 and all(k.endswith("_ragged") and "f32io_f64" in k for k in mb.kernels), mb.kernels
+    mb.run()
+    torch.cuda.synchronize()
+    for ps in mb.buckets:
+        o, m = ps.desc.order, 2 * ps.desc.order
+        co = ps.out.double()                                        # [sum S, 3, m]
+        assert bool(torch.isfinite(co).all())
+        off = ps.off
+        lens = off[1:] - off[:-1]
+        seg_traj = torch.repeat_interleave(torch.arange(lens.numel(), device=co.device), lens)   # trajectory of each segment
+        wp = ps.wp.double()                                         # [sum S + B, 3]
+        seg_idx = torch.arange(co.shape[0], device=co.device)
+        p_start = wp[seg_idx + seg_traj]                            # waypoint at each segment's start
+        p_end = wp[seg_idx + seg_traj + 1]
+        T = ps.tm.double()[:, None].expand(-1, 3)
+        # fp32 coefficients: a value of the polynomial is only as good as 6e-8 x the sum of the magnitudes of its terms
+        # (they cancel), so every check is scaled by that sum
+        def mag_at(t, j):
+            return _deriv_at(torch, co.abs(), t, j, o)
+        eps = 4e-7
+        assert float((co[..., m - 1] - p_start).abs().max()) == 0.0                      # constant term = waypoint, bit for bit (fp32)
+        assert bool(((_deriv_at(torch, co, T, 0, o) - p_end).abs() <= eps * mag_at(T, 0)).all())
+        first = torch.zeros(co.shape[0], dtype=torch.bool, device=co.device)
+        first[off[:-1]] = True
+        last = torch.zeros_like(first)
+        last[off[1:] - 1] = True
+        zero = torch.zeros_like(T)
+        for j in (1, 2):
+            end, start = _deriv_at(torch, co, T, j, o), _deriv_at(torch, co, zero, j, o)
+            m_end, m_start = mag_at(T, j), mag_at(zero, j)
+            inner = ~last[:-1]                                       # segment i and i+1 belong to the same trajectory
+            gap = (end[:-1] - start[1:]).abs()
+            assert bool((gap[inner] <= eps * (m_end[:-1] + m_start[1:])[inner] + 1e-30).all()), (o, j)
+            assert float(start[first].abs().max()) == 0.0, (o, j)    # zero boundary velocity / acceleration at the start: exact
+            assert bool((end[last].abs() <= eps * m_end[last]).all()), (o, j)
+    idx = np.linspace(0, B - 1, 192).astype(np.int64)
+    z = np.zeros((2, 3))
+    worst = {3: 0.0, 4: 0.0, 5: 0.0}
+    for i in idx:
+        o, w, t = trajs[i]
+        w32, t32 = w.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
+        ref, _ = oracle_mod.solve(o, w32, z, z, t32, long_double=True)
+        got = mb.coeffs(int(i)).double().cpu().numpy().reshape(ref.shape)
+        worst[o] = max(worst[o], float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
+    print("C5 full size, 192 of 65536 trajectories vs the 80-bit oracle (norm-wise, fp32 storage):", worst)
+    assert all(v < 1e-6 for v in worst.values()), worst
