@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error", "csp_minsnap_release_cached_memory",
     "csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch",
     "csp_alt_workspace_bytes", "csp_alt_optimize_heights_batch", "csp_alt_global_smooth_batch",
+    "csp_bezier_generate_batch",
 )
 
 
@@ -567,3 +568,36 @@ def alt_global_smooth_batch(input_z, xyz, offsets, lambda_smooth=1.0, max_climb_
     _check(_lib.csp_alt_global_smooth_batch(input_z.ctypes.data, xyz.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
                                             ctypes.byref(p), out.ctypes.data, solves.ctypes.data, None, 0, MEM_HOST, -1, None))
     return out, solves
+
+
+_lib.csp_bezier_generate_batch.restype = ctypes.c_int
+_lib.csp_bezier_generate_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32,
+                                           ctypes.c_void_p]
+
+
+def bezier_generate_batch(waypoints, offsets, resolution=1.0, min_radius=1.0, capacity=4096):
+    """Batched math_util::Bezier::GenerateTrajectoryMatrix (math_util/bezier.cpp:127-190; include/csp_bezier.h).
+    waypoints [total,3] (paths concatenated), offsets [B+1] point prefix sums; numpy (host) or torch CUDA tensors.
+    Returns (samples [B,capacity,3], counts [B])."""
+    if _is_torch(waypoints):
+        import torch
+        dev = waypoints.device
+        wp = waypoints.to(torch.float64).contiguous()
+        off = offsets.to(device=dev, dtype=torch.int64).contiguous()
+        B = off.numel() - 1
+        samples = torch.zeros((B, capacity, 3), dtype=torch.float64, device=dev)
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _check(_lib.csp_bezier_generate_batch(wp.data_ptr(), off.data_ptr(), B, float(resolution), float(min_radius), int(capacity),
+                                              samples.data_ptr(), counts.data_ptr(), MEM_DEVICE,
+                                              dev.index if dev.index is not None else -1, ctypes.c_void_p(st)))
+        return samples, counts
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    B = off.shape[0] - 1
+    samples = np.zeros((B, capacity, 3))
+    counts = np.empty(B, dtype=np.int32)
+    _check(_lib.csp_bezier_generate_batch(wp.ctypes.data, off.ctypes.data, B, float(resolution), float(min_radius), int(capacity),
+                                          samples.ctypes.data, counts.ctypes.data, MEM_HOST, -1, None))
+    return samples, counts

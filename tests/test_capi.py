@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     syms = set()
-    for h in ("csp_minsnap.h", "csp_geo.h", "csp_alt.h"):
+    for h in ("csp_minsnap.h", "csp_geo.h", "csp_alt.h", "csp_bezier.h"):
         hdr = open(os.path.join(ROOT, "include", h)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-        syms |= set(re.findall(r"\b(csp_(?:minsnap|geo|alt)_[a-z0-9_]+)\s*\(", hdr))
+        syms |= set(re.findall(r"\b(csp_(?:minsnap|geo|alt|bezier)_[a-z0-9_]+)\s*\(", hdr))
     return sorted(syms)
 
 
