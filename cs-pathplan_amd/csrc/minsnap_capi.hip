@@ -445,33 +445,32 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
     if (!workspace || workspace_bytes < need) return CSP_ERR_WORKSPACE;
     const size_t solve_ws = align_up(ws_bytes(&g, gs, nullptr), 256);
     char *base = (char *)workspace + solve_ws;
-    double *vw = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
-    double *md = (double *)base;                                  base += align_up((size_t)s.B * 8, 256);
-    int32_t *iters = (int32_t *)base;                             base += align_up((size_t)s.B * 4, 256);
+    // the loop's per-trajectory state lives in the caller's output arrays where they were passed (no copy at the end)
+    double *vw = vel_zero_weight_out ? vel_zero_weight_out : (double *)base;   base += align_up((size_t)s.B * 8, 256);
+    double *md = max_dev ? max_dev : (double *)base;                           base += align_up((size_t)s.B * 8, 256);
+    int32_t *iters = iterations ? iterations : (int32_t *)base;                base += align_up((size_t)s.B * 4, 256);
     int32_t *done = (int32_t *)base;                              base += align_up((size_t)s.B * 4, 256);
-    int32_t *pending = (int32_t *)base;                           base += 256;
+    int32_t *pending = (int32_t *)base;                           base += 256;   // cumulative count of weight increases
     // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
     int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
-    if ((e = csp::launch_resolve_init(vw, iters, done, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+    if ((e = csp::launch_resolve_init(vw, iters, done, pending, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+    int32_t increased_before = 0;
     if (desc->vel_zero_weight_per_traj)
         CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     for (int pass = 0; pass <= 10; ++pass) {  // at most 11 solves (:78-90)
         rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done,
                       tau_buf, pass == 0 ? 1 : 2);
         if (rc != CSP_OK) return rc;
-        if (sync_early_exit) CSP_HIP(hipMemsetAsync(pending, 0, 4, st));
         if ((e = csp::launch_resolve_update(md, vw, iters, done, sync_early_exit ? pending : nullptr, s.B, st)) != hipSuccess)
             return hip_fail(e, "resolve_update");
         if (sync_early_exit) {
-            int32_t left = 0;
-            CSP_HIP(hipMemcpyAsync(&left, pending, 4, hipMemcpyDeviceToHost, st));
+            int32_t increased = 0;   // cumulative: a pass that raised nobody's weight was the last one anybody needed
+            CSP_HIP(hipMemcpyAsync(&increased, pending, 4, hipMemcpyDeviceToHost, st));
             CSP_HIP(hipStreamSynchronize(st));
-            if (left == 0) break;
+            if (increased == increased_before) break;
+            increased_before = increased;
         }
     }
-    if (max_dev) CSP_HIP(hipMemcpyAsync(max_dev, md, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
-    if (vel_zero_weight_out) CSP_HIP(hipMemcpyAsync(vel_zero_weight_out, vw, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
-    if (iterations) CSP_HIP(hipMemcpyAsync(iterations, iters, (size_t)s.B * 4, hipMemcpyDeviceToDevice, st));
     return CSP_OK;
 }
 

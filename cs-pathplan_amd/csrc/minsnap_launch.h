@@ -68,7 +68,7 @@ struct TimeAllocArgs {
 hipError_t launch_time_alloc(const TimeAllocArgs &a, bool f32, hipStream_t st);
 
 // Re-solve loop bookkeeping (minimum_snap.cpp:80-90) and polynomial sampling (:97-205), minsnap_plan.hip
-hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, double vw0, int64_t B, hipStream_t st);
+hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, int32_t *pending, double vw0, int64_t B, hipStream_t st);
 hipError_t launch_fill_f64(double *p, double v, int64_t n, hipStream_t st);
 hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int32_t *pending, int64_t B,
                                  hipStream_t st);

@@ -10,8 +10,10 @@
 
 namespace csp {
 
-__global__ void __launch_bounds__(256) resolve_init_kernel(double *vw, int32_t *iters, int32_t *done, double vw0, int64_t B) {
+__global__ void __launch_bounds__(256) resolve_init_kernel(double *vw, int32_t *iters, int32_t *done, int32_t *pending, double vw0,
+                                                           int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && pending) *pending = 0;
     if (b >= B) return;
     vw[b] = vw0;
     iters[b] = 0;
@@ -42,9 +44,9 @@ hipError_t launch_fill_f64(double *p, double v, int64_t n, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, double vw0, int64_t B, hipStream_t st) {
+hipError_t launch_resolve_init(double *vw, int32_t *iters, int32_t *done, int32_t *pending, double vw0, int64_t B, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(resolve_init_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, vw, iters, done, vw0, B);
+    hipLaunchKernelGGL(resolve_init_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, vw, iters, done, pending, vw0, B);
     return hipGetLastError();
 }
 hipError_t launch_resolve_update(const double *max_dev, double *vw, int32_t *iters, int32_t *done, int32_t *pending, int64_t B,
