@@ -558,15 +558,47 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     const size_t m = 2 * (size_t)s.order;
     const size_t n_tm = (size_t)total_seg * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
     const size_t n_sm = (size_t)s.B * (size_t)capacity * 3 * s.elt;
+    // A few long flights (the reference's own call: ONE flight of kilometre legs): one wave per SEGMENT into per-segment
+    // runs, then placement + end-point rule + statistics (minsnap_plan.hip sample_wave_seg_kernel).  Needs fp64 storage,
+    // the default layout and a `capacity` that holds every candidate (the class shim passes exactly that), so that no run
+    // and no trajectory can overflow.
+    std::vector<int64_t> run_off;
+    if (a.long_segments && !a.one_lane && !s.f32 && !a.seg_major && s.B <= 64 && total_seg >= 2) {
+        run_off.resize((size_t)total_seg + 1);
+        run_off[0] = 0;
+        bool fits = true;
+        int64_t g = 0;
+        for (int64_t b = 0; b < s.B && fits; ++b) {
+            const int64_t nseg = s.ragged ? desc->seg_offsets[b + 1] - desc->seg_offsets[b] : s.S;
+            int64_t traj = 2;
+            for (int64_t k = 0; k < nseg; ++k, ++g) {
+                const double T = ((const double *)times)[g];
+                int64_t cand = 0;
+                if (T >= 1.0e-14 && T <= 1.0e7) cand = (int64_t)((T + 1e-12) / (T / 10.0 < 0.1 ? T / 10.0 : 0.1)) + 2;
+                run_off[(size_t)g + 1] = run_off[(size_t)g] + cand + 3;   // + first sample, + the parked end point, + slack
+                traj += cand;
+            }
+            fits = traj <= capacity;
+        }
+        if (!fits) run_off.clear();
+    }
     csp::HostCall hc(current_device(), st);
     const size_t o_tm = hc.in(times, n_tm), o_co = hc.in(coeffs, n_co);
     const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_ro = !run_off.empty() ? hc.in(run_off.data(), run_off.size() * 8) : 0;
     const size_t o_ct = hc.out(counts, (size_t)s.B * 4), o_sx = hc.out(stats, (size_t)s.B * 16);
     const size_t o_sm = hc.out(s.B == 1 ? nullptr : samples, n_sm);   // one flight: copied back below, only the rows in use
+    const size_t o_tmp = !run_off.empty() ? hc.scratch((size_t)run_off.back() * 24) : 0;
+    const size_t o_sc = !run_off.empty() ? hc.scratch((size_t)total_seg * 4) : 0;
     CSP_HIP(hc.upload());
     a.times = hc.ptr(o_tm); a.coeffs = hc.ptr(o_co); a.seg_off = s.ragged ? hc.ptr<const int64_t>(o_so) : nullptr;
     a.samples = hc.ptr(o_sm); a.counts = hc.ptr<int32_t>(o_ct); a.stats = hc.ptr<double>(o_sx);
-    hipError_t e = csp::launch_sample(a, s.f32, st);
+    hipError_t e;
+    if (!run_off.empty()) {
+        e = csp::launch_sample_segment_waves(a, hc.ptr<double>(o_tmp), hc.ptr<const int64_t>(o_ro), hc.ptr<int32_t>(o_sc), total_seg, st);
+    } else {
+        e = csp::launch_sample(a, s.f32, st);
+    }
     if (e != hipSuccess) return hip_fail(e, "sample launch");
     if (s.B == 1) {
         // one flight: `capacity` is an upper bound (every candidate); fetch the count first and then only the rows in use

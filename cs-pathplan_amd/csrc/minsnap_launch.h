@@ -92,5 +92,11 @@ struct SampleArgs {
     double keep_dist2;
 };
 hipError_t launch_sample(const SampleArgs &a, bool f32, hipStream_t st);
+// One WAVE PER SEGMENT for a few long flights (fp64 storage, `capacity` >= every candidate): segments thin independently
+// (the reference restarts its reference point at every segment, minimum_snap.cpp:128-133) into per-segment runs of `tmp`
+// (tmp_off[g] .. , sized by the caller from the host-resident times, last slot of the trajectory's last segment = p(T)),
+// a second kernel places the runs, applies the end-point rule and counts, the statistics kernel follows.
+hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
+                                       int64_t total_segments, hipStream_t st);
 
 }  // namespace csp

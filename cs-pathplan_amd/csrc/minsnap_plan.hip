@@ -560,6 +560,187 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One wave per SEGMENT (a few long flights from host memory -- the reference's own call: one flight, six kilometre
+// legs, 3600 candidates): the candidate search of sample_wave_kernel for one segment, recording into the segment's own
+// run of `tmp`.  Nothing crosses segments here: the first-sample rule concerns a trajectory's first segment only, the
+// end-point rule and the statistics are applied after the runs have been placed (sample_place_kernel,
+// sample_stats_kernel).  Same accumulated candidate times, same squared-distance test, same chain: the recorded
+// samples are bitwise those of the other samplers.
+template <int O>
+__global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts) {
+    constexpr int M = 2 * O;
+    __shared__ double lc[3 * 64];
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;                 // global segment
+    int64_t b, seg0;
+    int S;
+    if (a.seg_off) {                              // few trajectories: a linear search is fine
+        b = 0;
+        while (b + 1 < a.B && a.seg_off[b + 1] <= g) ++b;
+        seg0 = a.seg_off[b];
+        S = (int)(a.seg_off[b + 1] - seg0);
+    } else { b = g / a.S; seg0 = b * (int64_t)a.S; S = a.S; }
+    const int seg = (int)(g - seg0);
+    double *out = tmp + tmp_off[g] * 3;
+    const int64_t room = tmp_off[g + 1] - tmp_off[g];
+    const double *rec = (const double *)a.coeffs + g * 3 * M;
+    double c[3][M];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int k = 0; k < M; ++k) c[ax][k] = rec[ax * M + k];
+    const double T = ((const double *)a.times)[g];
+    double dt = 0.1;
+    if (dt > T / 10.0) dt = T / 10.0;
+    auto bcast = [](double v, int src) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    const double sd2 = a.keep_dist2;
+    int64_t n = 0;
+    double prev[3];
+    eval_poly<M>(c, 0.0, prev);
+    if (seg == 0) {                               // the trajectory's very first sample (:128-133, n == 0)
+        if (lane < 3 && n < room) out[n * 3 + lane] = prev[lane == 0 ? 0 : lane == 1 ? 1 : 2];
+        ++n;
+    }
+    bool dense = false;
+    double tb = dt;
+    while (tb <= t_end(T)) {
+        double t = tb;
+        for (int i = 0; i < 63; ++i) {
+            if (lane > i) t += dt;
+        }
+        const double run = bcast(t, 63) + dt;
+        const bool exists = t <= t_end(T);
+        double cur[3];
+        eval_poly<M>(c, t < T ? t : T, cur);
+        double dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+        const unsigned long long keep = __builtin_amdgcn_ballot_w64(exists && (dx * dx + dy * dy + dz * dz >= sd2));
+        if (keep != 0) {
+            int l = __builtin_ctzll(keep);
+            unsigned long long kept = 0;
+            int nxt = 64;
+            constexpr int LA = 16;
+            if (dense) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 3; ++q) lc[q * 64 + lane] = cur[q];
+                __syncthreads();
+                const int E = __builtin_popcountll(__builtin_amdgcn_ballot_w64(exists));
+                for (int s2 = 1; s2 <= LA; ++s2) {
+                    const int m = lane + s2;
+                    if (m < E && nxt == 64) {
+                        const double ex = lc[m] - cur[0], ey = lc[64 + m] - cur[1], ez = lc[128 + m] - cur[2];
+                        if (ex * ex + ey * ey + ez * ez >= sd2) nxt = m;
+                    }
+                }
+            }
+            for (;;) {
+                l = __builtin_amdgcn_readfirstlane(l);
+                kept |= 1ull << l;
+                if (dense) {
+                    const int nx = __builtin_amdgcn_readlane(nxt, l);
+                    if (nx < 64) { l = nx; continue; }
+                }
+                double pl[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pl[q] = bcast(cur[q], l);
+                dx = cur[0] - pl[0]; dy = cur[1] - pl[1]; dz = cur[2] - pl[2];
+                const unsigned long long more = __builtin_amdgcn_ballot_w64(exists && lane > l + (dense ? LA : 0) &&
+                                                                           (dx * dx + dy * dy + dz * dz >= sd2));
+                if (more == 0) break;
+                l = __builtin_ctzll(more);
+            }
+            const int cnt = __builtin_popcountll(kept);
+            if ((kept >> lane) & 1ull) {
+                const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                if (n + rank < room) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) out[(n + rank) * 3 + q] = cur[q];
+                }
+            }
+            const int lastl = 63 - __builtin_clzll(kept);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) prev[q] = bcast(cur[q], lastl);
+            n += cnt;
+            dense = cnt >= 4;
+        } else {
+            dense = false;
+        }
+        tb = run;
+    }
+    if (seg == S - 1) {   // the end point p(T), for the end-point rule: parked in the run's LAST slot (never reached by samples)
+        double pe[3];
+        eval_poly<M>(c, T, pe);
+        if (lane < 3) out[(room - 1) * 3 + lane] = pe[lane == 0 ? 0 : lane == 1 ? 1 : 2];
+    }
+    if (lane == 0) seg_counts[g] = (int32_t)n;
+}
+
+// Places the per-segment runs of sample_wave_seg_kernel: one wave per trajectory; prefix sum of the segment counts, coalesced
+// copies, the end-point rule (:157-160: present unless it duplicates the last recorded sample), the count.
+__global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts) {
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    int64_t seg0;
+    int S;
+    if (a.seg_off) { seg0 = a.seg_off[b]; S = (int)(a.seg_off[b + 1] - seg0); }
+    else { seg0 = b * (int64_t)a.S; S = a.S; }
+    double *out = (double *)a.samples + b * a.capacity * 3;
+    int64_t n = 0;
+    for (int seg = 0; seg < S; ++seg) {
+        const int64_t g = seg0 + seg;
+        const int cnt = seg_counts[g];
+        const double *src = tmp + tmp_off[g] * 3;
+        for (int64_t e = lane; e < (int64_t)cnt * 3; e += 64)
+            if (n * 3 + e < a.capacity * 3) out[n * 3 + e] = src[e];
+        n += cnt;
+    }
+    if (S > 0) {
+        const int64_t gl = seg0 + S - 1;
+        const double *pe = tmp + (tmp_off[gl + 1] - 1) * 3;
+        bool add = n == 0;
+        if (n > 0) {
+            // the last recorded sample: the last one of the last non-empty run
+            int sl = S - 1;
+            while (sl > 0 && seg_counts[seg0 + sl] == 0) --sl;
+            const double *lp = tmp + (tmp_off[seg0 + sl] + seg_counts[seg0 + sl] - 1) * 3;
+            const double dx = lp[0] - pe[0], dy = lp[1] - pe[1], dz = lp[2] - pe[2];
+            add = sqrt(dx * dx + dy * dy + dz * dz) > 1e-6;
+        }
+        if (add) {
+            if (lane < 3 && n < a.capacity) out[n * 3 + lane] = pe[lane];
+            ++n;
+        }
+    }
+    if (lane == 0) {
+        a.counts[b] = (int32_t)n;
+        if (a.stats) { a.stats[b * 2] = 0.0; a.stats[b * 2 + 1] = 1.0e12; }   // overwritten by sample_stats_kernel (n <= capacity here)
+    }
+}
+
+hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
+                                       int64_t total_segments, hipStream_t st) {
+    if (a.B == 0 || total_segments == 0) return hipSuccess;
+    const dim3 grid((unsigned)total_segments), block(64);
+    switch (a.order) {
+        case 1: hipLaunchKernelGGL((sample_wave_seg_kernel<1>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        case 2: hipLaunchKernelGGL((sample_wave_seg_kernel<2>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        case 3: hipLaunchKernelGGL((sample_wave_seg_kernel<3>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        case 4: hipLaunchKernelGGL((sample_wave_seg_kernel<4>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        case 5: hipLaunchKernelGGL((sample_wave_seg_kernel<5>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), block, 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);
+    if (a.stats)
+        hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, st, (const double *)a.samples, a.counts,
+                           a.stats, a.B, a.capacity);
+    return hipGetLastError();
+}
+
 template <typename IO> static hipError_t launch_sample_t(const SampleArgs &a, hipStream_t st) {
     if (a.long_segments && !a.one_lane) {   // one wave per trajectory, 64 candidates per round
         const dim3 grid((unsigned)a.B), block(64);
