@@ -26,22 +26,37 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(batch, world, rank):
-    """Contiguous chunk [lo, hi) of rank `rank`; the first batch % world ranks get one extra."""
-    base, extra = divmod(int(batch), int(world))
+def shard_bounds(batch, world, rank, align=1):
+    """Contiguous chunk [lo, hi) of rank `rank`; the first batch % world ranks get one extra.  With `align` > 1 every
+    interior boundary is a multiple of `align` (the register-resident kernels read 16-byte pieces: a slice of a
+    [B][S+1][3] array that starts at an odd trajectory is not 16-byte aligned)."""
+    batch, world, align = int(batch), int(world), int(align)
+    if align > 1:
+        units = (batch + align - 1) // align
+        lo, hi = shard_bounds(units, world, rank)
+        return min(lo * align, batch), min(hi * align, batch)
+    base, extra = divmod(batch, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def chunk_bounds(lo, hi, chunks):
-    """[lo, hi) cut into `chunks` contiguous balanced pieces (empty pieces dropped)."""
+def chunk_bounds(lo, hi, chunks, align=1):
+    """[lo, hi) cut into `chunks` contiguous balanced pieces (empty pieces dropped); interior boundaries are multiples of
+    `align` relative to `lo` (which the caller keeps aligned)."""
     n = hi - lo
+    units = (n + align - 1) // align
     out = []
     for c in range(chunks):
-        a, b = lo + n * c // chunks, lo + n * (c + 1) // chunks
+        a, b = lo + min(units * c // chunks * align, n), lo + min(units * (c + 1) // chunks * align, n)
         if b > a:
             out.append((a, b))
     return out
+
+
+def boundary_alignment(total, world, chunks):
+    """Whole 64-trajectory slices per piece when the batch is big enough for that, otherwise multiples of 4 trajectories
+    (enough for 16-byte alignment of fp64 and fp32 rows of any segment count)."""
+    return 64 if total >= 64 * world * chunks else 4
 
 
 def _default_local_solve(order, path_weight=0.0, vel_zero_weight=0.0):
@@ -83,10 +98,11 @@ class RootPipeline:
         self.dev, self.dist, self.rank, self.world, self.group, self.root = device, dist, rank, world, group, root
         self.per_bc, self.dtype = bool(per_trajectory_bc), dtype
         self.solve = local_solve or _default_local_solve(order, path_weight, vel_zero_weight)
-        self.lo, self.hi = shard_bounds(self.total, world, rank)
+        self.chunks = max(1, int(chunks))
+        self.align = boundary_alignment(self.total, world, self.chunks)
+        self.lo, self.hi = shard_bounds(self.total, world, rank, self.align)
         self.local_count = self.hi - self.lo
-        self.chunks = max(1, min(int(chunks), max(1, self.local_count)))
-        self.my_chunks = chunk_bounds(self.lo, self.hi, self.chunks)
+        self.my_chunks = chunk_bounds(self.lo, self.hi, self.chunks, self.align)
         n = self.local_count
         if rank == root:
             self.out = torch.empty((self.total, self.S, 3, self.m), dtype=dtype, device=device)
@@ -114,7 +130,7 @@ class RootPipeline:
                 for c in range(self.chunks):
                     ops = []
                     for r in self._peers():
-                        cb = chunk_bounds(*shard_bounds(self.total, self.world, r), self.chunks)
+                        cb = chunk_bounds(*shard_bounds(self.total, self.world, r, self.align), self.chunks, self.align)
                         if c < len(cb):
                             a, b = cb[c]
                             ops.append(d.P2POp(d.isend, waypoints[a:b], r, self.group))
@@ -126,7 +142,7 @@ class RootPipeline:
                 for c in range(self.chunks):
                     ops = []
                     for r in self._peers():
-                        cb = chunk_bounds(*shard_bounds(self.total, self.world, r), self.chunks)
+                        cb = chunk_bounds(*shard_bounds(self.total, self.world, r, self.align), self.chunks, self.align)
                         if c < len(cb):
                             a, b = cb[c]
                             ops.append(d.P2POp(d.irecv, self.out[a:b], r, self.group))

@@ -67,3 +67,26 @@ def test_bench_rccl_control_flow_on_one_rank():
                env={"CSP_BENCH_FORCE_DIST": "1"})
     assert res["n_gpus"] == 1 and res["value"] > 1e8
     assert res["roofline"]["kernel"] == "fixed_o4_s16_f64"
+
+
+def test_bench_strong_scaling_divides_one_batch():
+    """--scaling strong: ONE batch of --batch trajectories cut into contiguous balanced chunks over the ranks (two ranks
+    rehearsed on one GPU over gloo)."""
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+              "127.0.0.1", "--master-port", "29561", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2",
+              "--batch", "8192", "--scaling", "strong"], env={"CSP_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["batch_per_gpu"] == 4096 and d["value"] > 0
+
+
+def test_bench_end_to_end_pipeline_on_one_rank():
+    """--end-to-end through the RCCL-initialised path with one rank (CSP_BENCH_FORCE_DIST=1): the root pipeline degenerates to
+    the chunked local solve and must reproduce the one-call result bit for bit; the record carries the byte counts."""
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                "--master-addr", "127.0.0.1", "--master-port", "29563",
+                "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-side-records",
+                "--end-to-end", "--e2e-chunks", "3", "--batch", "10000"],
+               env={"CSP_BENCH_FORCE_DIST": "1"})
+    e = res["end_to_end"]
+    assert e["bit_equal_to_one_device"] is True and e["total_batch"] == 10000 and e["solves_per_s"] > 0
+    assert e["bytes_scattered_per_step"] == 0 and e["bytes_gathered_per_step"] == 0   # one rank: nothing travels
