@@ -563,10 +563,22 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
         const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
         const int n_wp = rows * L::WP_ROW / 2;  // 16-byte pieces
         constexpr int WP_ITERS = (64 * L::WP_ROW / 2 + 127) / 128;
+        // Branch-free: pieces beyond the slice are clamped to its last piece (re-writing that piece with its own value)
+        // instead of being skipped.  With a conditional per piece every load sat in its own basic block and hipcc
+        // emitted load -> s_waitcnt vmcnt(0) -> ds_write thirteen times in a row: thirteen exposed memory round trips
+        // at the start of every workgroup.  As one block the loads are all in flight before the first wait.
+        {
+            double2 v[WP_ITERS];
 #pragma unroll
-        for (int it = 0; it < WP_ITERS; ++it) {
-            const int c = it * 128 + tid;
-            if (c < n_wp) reinterpret_cast<double2 *>(l_wp)[c] = g_wp[c];
+            for (int it = 0; it < WP_ITERS; ++it) {
+                const int c = it * 128 + tid;
+                v[it] = g_wp[c < n_wp ? c : n_wp - 1];
+            }
+#pragma unroll
+            for (int it = 0; it < WP_ITERS; ++it) {
+                const int c = it * 128 + tid;
+                reinterpret_cast<double2 *>(l_wp)[c < n_wp ? c : n_wp - 1] = v[it];
+            }
         }
         if ((rows * L::WP_ROW) & 1) {  // odd number of doubles: last one by itself
             if (tid == 0) l_wp[rows * L::WP_ROW - 1] = ((const double *)a.wp + b0 * L::WP_ROW)[rows * L::WP_ROW - 1];
@@ -574,10 +586,18 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
         const double2 *g_tm = reinterpret_cast<const double2 *>((const double *)a.times + b0 * S);
         const int n_tm = rows * S / 2;  // 16-byte pieces
         constexpr int TM_ITERS = (64 * S / 2 + 127) / 128;
+        {
+            double2 v[TM_ITERS];
 #pragma unroll
-        for (int it = 0; it < TM_ITERS; ++it) {
-            const int c = it * 128 + tid;
-            if (c < n_tm) reinterpret_cast<double2 *>(l_tm)[c] = g_tm[c];
+            for (int it = 0; it < TM_ITERS; ++it) {
+                const int c = it * 128 + tid;
+                v[it] = g_tm[c < n_tm ? c : n_tm - 1];
+            }
+#pragma unroll
+            for (int it = 0; it < TM_ITERS; ++it) {
+                const int c = it * 128 + tid;
+                reinterpret_cast<double2 *>(l_tm)[c < n_tm ? c : n_tm - 1] = v[it];
+            }
         }
         if ((rows * S) & 1) {
             if (tid == 0) l_tm[rows * S - 1] = ((const double *)a.times + b0 * S)[rows * S - 1];
