@@ -39,17 +39,42 @@ template <typename IO> __device__ __forceinline__ double ld(const IO *p) { retur
 
 // This lane's chunk: c segments starting at segment s0 of a trajectory whose first segment is seg0
 // (global, ragged prefix) and whose first waypoint is point seg0 + b.  REV loads it time-reversed.
+// Inside an active lane every load is issued unconditionally (indices clamped into the chunk, the unused slots overwritten
+// by a select afterwards): with `(i < c) ? load : constant` hipcc put every load into a basic block of its own and
+// followed it with s_waitcnt vmcnt(0) -- 19 exposed memory round trips per call, three calls per lane, which was more
+// than half of a wave's life.
 template <typename IO, bool REV>
 __device__ __forceinline__ void load_chunk(const IO *wp, const IO *tm, int64_t pt0, int64_t sg0, int c,
                                            double (&T)[CMAX], double (&P)[CMAX + 1][3]) {
+    IO t[CMAX], p[CMAX + 1][3];
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) T[i] = (i < c) ? ld(tm + sg0 + (REV ? c - 1 - i : i)) : 1.0;
+    for (int i = 0; i < CMAX; ++i) {
+        t[i] = (IO)1;
 #pragma unroll
-    for (int i = 0; i <= CMAX; ++i) {
-        const int64_t q = pt0 + (REV ? c - i : i);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) P[i][ax] = (i <= c) ? ld(wp + q * 3 + ax) : 0.0;
+        for (int ax = 0; ax < 3; ++ax) p[i][ax] = (IO)0;
     }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) p[CMAX][ax] = (IO)0;
+    if (c > 0) {   // ONE branch per call (idle lanes touch no memory), none per load
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            const int ii = i < c ? i : c - 1;
+            t[i] = tm[sg0 + (REV ? c - 1 - ii : ii)];
+        }
+#pragma unroll
+        for (int i = 0; i <= CMAX; ++i) {
+            const int ii = i <= c ? i : c;
+            const int64_t q = pt0 + (REV ? c - ii : ii);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) p[i][ax] = wp[q * 3 + ax];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) T[i] = (i < c) ? (double)t[i] : 1.0;
+#pragma unroll
+    for (int i = 0; i <= CMAX; ++i)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) P[i][ax] = (i <= c) ? (double)p[i][ax] : 0.0;
 }
 
 // Step 1.  Eliminates the chunk's interior waypoints in local order with the START interface x_s as a
