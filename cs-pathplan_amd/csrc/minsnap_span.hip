@@ -118,7 +118,10 @@ __device__ __forceinline__ bool span_schur(const SpanView<IO> &v, double vw, dou
     for (int k = 1; k < c; ++k) {
         const double Tk = Tn;
         double Pk[3] = {Pc[0], Pc[1], Pc[2]};
-        if (k + 1 < c) { Tn = v.T(k + 1); v.P(k + 2, Pc); }
+        // the NEXT step's inputs, requested now and needed one iteration later.  Unconditional (index clamped to the last
+        // step) on purpose: inside `if (k + 1 < c)` hipcc waited for the loads right there (s_waitcnt vmcnt(0) at the end of
+        // the conditional block), which put one memory round trip on every elimination step
+        { const int kn = k + 1 < c ? k + 1 : c - 1; Tn = v.T(kn); v.P(kn + 1, Pc); }
         seg_make<O>(Tk, vw, right);
         spd &= elim_step<O, CROSS>(left, right, Pa, Pb, Pk, W, z, V);
         left = right;
@@ -188,15 +191,20 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
     // their first touch would pay one HBM latency per cache line, serially.  Touch every line once,
     // all loads in flight together (one waypoint coordinate each: waypoints are 24 B apart).
     {
-        double sink = 0.0, tv[CSEG + 1], tt[CSEG / 4];
+        // (ONE branch for the lane, indices clamped into the span: a conditional per load would make hipcc wait for each
+        // of them in turn -- the opposite of what this step is for)
+        IO tv[CSEG + 1], tt[CSEG / 4];
+        double sink = 0.0;
+        if (active && c > 0) {
 #pragma unroll
-        for (int i = 0; i <= CSEG; ++i) tv[i] = (i <= c && active) ? ld(wp + (pt0 + i) * 3) : 0.0;
+            for (int i = 0; i <= CSEG; ++i) tv[i] = wp[(pt0 + (i <= c ? i : c)) * 3];
 #pragma unroll
-        for (int i = 0; i < CSEG / 4; ++i) tt[i] = (4 * i < c) ? ld(tm + sg0 + 4 * i) : 0.0;
+            for (int i = 0; i < CSEG / 4; ++i) tt[i] = tm[sg0 + (4 * i < c ? 4 * i : c - 1)];
 #pragma unroll
-        for (int i = 0; i <= CSEG; ++i) sink += tv[i];
+            for (int i = 0; i <= CSEG; ++i) sink += (double)tv[i];
 #pragma unroll
-        for (int i = 0; i < CSEG / 4; ++i) sink += tt[i];
+            for (int i = 0; i < CSEG / 4; ++i) sink += (double)tt[i];
+        }
         if (sink == 1.0e-300) xch[lane] = sink;   // never true for real data: keeps the loads alive
     }
 
@@ -344,7 +352,7 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
             for (int k = 1; k < lo; ++k) {
                 const double Tk = Tn;
                 double Pk[3] = {Pc[0], Pc[1], Pc[2]};
-                if (k + 1 < hi) { Tn = fv.T(k + 1); fv.P(k + 2, Pc); }
+                { const int kn = k + 1 < hi ? k + 1 : hi - 1; Tn = fv.T(kn); fv.P(kn + 1, Pc); }   // unconditional, see span_schur
                 seg_make<O>(Tk, vw, right);
                 spd &= elim_step<O, false>(left, right, Pa, Pb, Pk, W, z, unusedV);
                 left = right;
@@ -357,7 +365,7 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
                 if (k >= 1) {
                     const double Tk = Tn;
                     double Pk[3] = {Pc[0], Pc[1], Pc[2]};
-                    if (k + 1 < hi) { Tn = fv.T(k + 1); fv.P(k + 2, Pc); }
+                    { const int kn = k + 1 < hi ? k + 1 : hi - 1; Tn = fv.T(kn); fv.P(kn + 1, Pc); }
                     seg_make<O>(Tk, vw, right);
                     spd &= elim_step<O, false>(left, right, Pa, Pb, Pk, W, z, unusedV);
                     left = right;
