@@ -414,13 +414,20 @@ namespace {
 int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoints, double v_avg, double min_time_s,
                 const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
                 int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes, hipStream_t st,
-                bool sync_early_exit) {
+                bool sync_early_exit, int phase = 0, int32_t *pending_ext = nullptr) {
+    // phase 0: everything (device-memory callers; host callers that check after every pass).  The host wrapper splits the
+    // call so that the common case -- every trajectory converged at its FIRST solve -- costs one synchronisation:
+    // phase 1 = time allocation + first solve + bookkeeping, nothing synchronised (the "increases so far" counter sits in
+    // the caller's output block and comes back with the results); phase 2 = the remaining <= 10 passes, checked per pass.
     int rc;
-    csp::TimeAllocArgs ta;
-    ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
-    ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
-    hipError_t e = csp::launch_time_alloc(ta, s.f32, st);
-    if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
+    hipError_t e;
+    if (phase != 2) {
+        csp::TimeAllocArgs ta;
+        ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+        ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
+        e = csp::launch_time_alloc(ta, s.f32, st);
+        if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
+    }
 
     if (!(desc->path_weight > 0.0)) {
         // without the path penalty the deviation metric is identically 0 (t* = 0, :342), so the
@@ -450,20 +457,28 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
     double *md = max_dev ? max_dev : (double *)base;                           base += align_up((size_t)s.B * 8, 256);
     int32_t *iters = iterations ? iterations : (int32_t *)base;                base += align_up((size_t)s.B * 4, 256);
     int32_t *done = (int32_t *)base;                              base += align_up((size_t)s.B * 4, 256);
-    int32_t *pending = (int32_t *)base;                           base += 256;   // cumulative count of weight increases
+    int32_t *pending = pending_ext ? pending_ext : (int32_t *)base;   base += 256;   // cumulative count of weight increases
     // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
     int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
-    if ((e = csp::launch_resolve_init(vw, iters, done, pending, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+    if (phase != 2) {
+        if ((e = csp::launch_resolve_init(vw, iters, done, pending, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+        if (desc->vel_zero_weight_per_traj)
+            CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
+    }
+    const bool count = sync_early_exit || phase != 0;
     int32_t increased_before = 0;
-    if (desc->vel_zero_weight_per_traj)
-        CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
-    for (int pass = 0; pass <= 10; ++pass) {  // at most 11 solves (:78-90)
+    if (phase == 2) {   // the counter after the first pass (the host wrapper has it too; read here to stay self-contained)
+        CSP_HIP(hipMemcpyAsync(&increased_before, pending, 4, hipMemcpyDeviceToHost, st));
+        CSP_HIP(hipStreamSynchronize(st));
+    }
+    const int first = phase == 2 ? 1 : 0, last = phase == 1 ? 0 : 10;
+    for (int pass = first; pass <= last; ++pass) {  // at most 11 solves (:78-90)
         rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done,
                       tau_buf, pass == 0 ? 1 : 2);
         if (rc != CSP_OK) return rc;
-        if ((e = csp::launch_resolve_update(md, vw, iters, done, sync_early_exit ? pending : nullptr, s.B, st)) != hipSuccess)
+        if ((e = csp::launch_resolve_update(md, vw, iters, done, count ? pending : nullptr, s.B, st)) != hipSuccess)
             return hip_fail(e, "resolve_update");
-        if (sync_early_exit) {
+        if (sync_early_exit && phase != 1) {
             int32_t increased = 0;   // cumulative: a pass that raised nobody's weight was the last one anybody needed
             CSP_HIP(hipMemcpyAsync(&increased, pending, 4, hipMemcpyDeviceToHost, st));
             CSP_HIP(hipStreamSynchronize(st));
@@ -509,14 +524,33 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
     const size_t o_tm = hc.out(times, n_tm), o_co = hc.out(coeffs, n_co);
     const size_t o_md = hc.out(max_dev, (size_t)s.B * 8), o_vw = hc.out(vel_zero_weight_out, (size_t)s.B * 8);
     const size_t o_it = hc.out(iterations, (size_t)s.B * 4), o_st = hc.out(status, (size_t)s.B * 4);
+    int32_t raised = 0;
+    const size_t o_pd = hc.out(&raised, 4);
     const size_t o_ws = hc.scratch(n_ws);
     CSP_HIP(hc.upload());
     if (s.ragged) dd.seg_offsets = hc.ptr<const int64_t>(o_so);
     dd.vel_zero_weight_per_traj = desc->vel_zero_weight_per_traj ? hc.ptr<const double>(o_vi) : nullptr;
+    if (!(desc->path_weight > 0.0)) {   // one solve, no loop
+        rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
+                         hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true);
+        if (rc != CSP_OK) return rc;
+        CSP_HIP(hc.download());
+        return CSP_OK;
+    }
+    // first solve, results and the "weights raised so far" counter in ONE copy back; only if somebody's weight was raised do
+    // the remaining passes run (checked one by one) and the results come back a second time
     rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
-                     hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true);
+                     hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true, 1,
+                     hc.ptr<int32_t>(o_pd));
     if (rc != CSP_OK) return rc;
     CSP_HIP(hc.download());
+    if (raised != 0) {
+        rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
+                         hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true, 2,
+                         hc.ptr<int32_t>(o_pd));
+        if (rc != CSP_OK) return rc;
+        CSP_HIP(hc.download());
+    }
     return CSP_OK;
 }
 
@@ -587,7 +621,11 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
     const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
     const size_t o_ro = !run_off.empty() ? hc.in(run_off.data(), run_off.size() * 8) : 0;
     const size_t o_ct = hc.out(counts, (size_t)s.B * 4), o_sx = hc.out(stats, (size_t)s.B * 16);
-    const size_t o_sm = hc.out(s.B == 1 ? nullptr : samples, n_sm);   // one flight: copied back below, only the rows in use
+    // one flight: `capacity` is an upper bound (every candidate).  Up to 1 MB it simply comes back with the count and the
+    // statistics in ONE copy (a second round trip costs more than the surplus rows); beyond that the count is fetched first
+    // and only the rows in use follow
+    const bool two_step = s.B == 1 && n_sm > ((size_t)1 << 20);
+    const size_t o_sm = hc.out(two_step ? nullptr : samples, n_sm);
     const size_t o_tmp = !run_off.empty() ? hc.scratch((size_t)run_off.back() * 24) : 0;
     const size_t o_sc = !run_off.empty() ? hc.scratch((size_t)total_seg * 4) : 0;
     CSP_HIP(hc.upload());
@@ -600,8 +638,7 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
         e = csp::launch_sample(a, s.f32, st);
     }
     if (e != hipSuccess) return hip_fail(e, "sample launch");
-    if (s.B == 1) {
-        // one flight: `capacity` is an upper bound (every candidate); fetch the count first and then only the rows in use
+    if (two_step) {
         CSP_HIP(hipMemcpyAsync(counts, hc.ptr(o_ct), 4, hipMemcpyDeviceToHost, st));
         CSP_HIP(hipStreamSynchronize(st));
         const int64_t rows = counts[0] < capacity ? (counts[0] > 0 ? counts[0] : 0) : capacity;
