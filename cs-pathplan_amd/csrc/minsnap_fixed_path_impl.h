@@ -16,6 +16,8 @@
 // +h_x*g with g = w*(P_s + (2*tau - h_endpos)*dP) per axis.  Everything is evaluated in the
 // role's own (possibly time-reversed) frame: the cost terms are frame independent.
 #pragma once
+#include <type_traits>
+
 #include "minsnap_fixed_impl.h"
 
 namespace csp {
@@ -68,11 +70,34 @@ template <int O> __device__ __forceinline__ double q_ee(const PSeg<O> &s, double
     return __builtin_fma(pw * s.h[O + r + 1], s.h[O + c + 1], Tab<O>::QT(O + r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c]);
 }
 
+// Dense residency (order 2, S >= 8): under 40 KB of LDS and 256 registers, so that FOUR workgroups share a CU.
+template <int O, int S> constexpr bool path_dense = (O == 2 && S >= 8);
+// doubles per staging row: the dense variant gives up the two padding doubles (2-way conflicts on its six
+// ds_write_b128 per segment, a few dozen clocks) for 2 KB of LDS
+template <int O, int S> constexpr int path_stage_row = path_dense<O, S> ? FixedLds<O, S>::REC : FixedLds<O, S>::STAGE_ROW;
+
+// Dense residency: a role's segment times live in registers for the whole kernel (waypoints still come from LDS), so
+// that the staging tiles can lie on top of the LDS image of the times.
+template <int S, bool BOTTOM> struct TimeRegInputs {
+    static constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;
+    double t[HS];
+    const double *l_wp;
+    int lane;
+    __device__ __forceinline__ void fill(const LdsInputs<S, BOTTOM> &in) {
+        l_wp = in.l_wp;
+        lane = in.lane;
+#pragma unroll
+        for (int j = 0; j < HS; ++j) t[j] = in.T(j);
+    }
+    __device__ __forceinline__ double T(int j) const { return t[j]; }
+    __device__ __forceinline__ double P(int j, int ax) const { return l_wp[lane * (S + 1) * 3 + (BOTTOM ? S - j : j) * 3 + ax]; }
+};
+
 // One full twisted sweep.  PEN = false: pass A (fills tau[]); PEN = true: pass B (stores, deviation).
 template <int O, int S, bool BOTTOM, bool PEN, bool STATUS, class In>
 __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int rows, int lane, const In &in,
                                            const RoleBc<BOTTOM> &rbc, double pw, const double *l_hw, double *stage,
-                                           double *partner_stage, const int *l_skip,
+                                           double *xchg, double *partner_xchg, const int *l_skip,
                                            int (&tau)[BOTTOM ? S / 2 : (S + 1) / 2], bool &spd,
                                            double &nanacc, double &maxdev) {
     constexpr int N = O - 1, M = 2 * O;
@@ -179,11 +204,11 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) partner_stage[(e++) * 64 + lane] = Cm[r][c];
+            for (int c = 0; c <= r; ++c) partner_xchg[(e++) * 64 + lane] = Cm[r][c];
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) partner_stage[(e++) * 64 + lane] = cm[r][ax];
+            for (int ax = 0; ax < 3; ++ax) partner_xchg[(e++) * 64 + lane] = cm[r][ax];
     }
     lds_barrier();
     double xn[N][3];
@@ -194,14 +219,14 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
         for (int r = 0; r < N; ++r)
 #pragma unroll
             for (int c = 0; c <= r; ++c) {
-                const double o = stage[(e++) * 64 + lane];
+                const double o = xchg[(e++) * 64 + lane];
                 Sm[r][c] = Cm[r][c] + (((r + c) & 1) ? -o : o);
             }
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                const double o = stage[(e++) * 64 + lane];
+                const double o = xchg[(e++) * 64 + lane];
                 R[r][ax] = cm[r][ax] + ((r & 1) ? o : -o);
             }
         spd &= SmallSpd<N, 3>::solve(Sm, R);
@@ -212,7 +237,7 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
     }
 
     // ---- backward sweep ----
-    constexpr int RECB = L::REC * 8, RS = S * RECB, ROW = L::STAGE_ROW;
+    constexpr int RECB = L::REC * 8, RS = S * RECB, ROW = path_stage_row<O, S>;
     const int grp = lane / L::LPR, lane_in = lane - grp * L::LPR;
     const int lds_off = grp * ROW + lane_in * 2;
     const unsigned g_off = (unsigned)(grp * RS + lane_in * 16);
@@ -351,20 +376,24 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
             {
                 // deviation / chord length (:612-616: chords of <= 1e-6 are skipped).
                 // Order 2: `maxdev` carries the SQUARED ratio (one square root per trajectory, in path_role: two square
-                // roots and a division per segment were a fifth of this short sweep), branch-free, so that the 8
-                // unrolled segments of a half form ONE scheduling region -- registers are plentiful at order 2 and
-                // the interleaving hides the fp64 latencies of a lone wave (46.8 us against 54.2 with a branch).
-                // Orders 3-4: the ratio itself, as one square root of the ratio of squares, inside a REAL branch
-                // (the empty asm keeps it one): it ends the basic block once per segment.  As one block the segments
-                // are register-allocated together and, with the stored factors filling most of the file, end in
-                // scratch (1.4 KB/lane at order 4, S = 16: 170 us instead of 98).
+                // roots and a division per segment were a fifth of this short sweep).
+                // Whether the test is a REAL branch (the empty asm keeps it one) decides the register allocation: a
+                // branch ends the basic block once per segment; without it the unrolled segments of a half form ONE
+                // scheduling region.
+                //  * order 2, S < 8: branch-free -- registers are plentiful and the interleaving hides the fp64
+                //    latencies of a lone wave (46.8 us against 54.2 with a branch at one wave per SIMD);
+                //  * order 2, S >= 8 (path_dense): branch -- 169 registers instead of 442, which is what lets two
+                //    waves share a SIMD (see the kernel);
+                //  * orders 3-4: branch -- as one block the segments are register-allocated together and, with the
+                //    stored factors filling most of the file, end in scratch (1.4 KB/lane at order 4, S = 16: 170 us
+                //    instead of 98).
                 double ratio = 0.0;
-                if constexpr (O == 2) {
+                if constexpr (O == 2 && !path_dense<O, S>) {
                     ratio = (len2 > 1e-12) ? d2 * fast_rcp(len2) : 0.0;
                 } else {
                     if (len2 > 1e-12) {
                         asm volatile("" ::: "memory");
-                        ratio = sqrt(d2 * fast_rcp(len2));
+                        ratio = O == 2 ? d2 * fast_rcp(len2) : sqrt(d2 * fast_rcp(len2));
                     }
                 }
                 maxdev = ratio > maxdev ? ratio : maxdev;
@@ -388,12 +417,17 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
     }
 }
 
-template <int O, int S, bool BOTTOM, bool STATUS>
+template <int O, int S, bool BOTTOM, bool STATUS, bool DENSE>
 __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int rows, int64_t b, int lane,
                                           const double *l_wp, const double *l_tm, const double *l_hw, double *stage,
-                                          double *partner_stage, const int *l_skip, double *l_dev, int *l_bits) {
+                                          double *xchg, double *partner_xchg, const int *l_skip, double *l_dev, int *l_bits) {
     constexpr int HS = BOTTOM ? S / 2 : (S + 1) / 2;
-    const LdsInputs<S, BOTTOM> in{l_wp, l_tm, lane};
+    const LdsInputs<S, BOTTOM> lin{l_wp, l_tm, lane};
+    // DENSE: the staging tiles lie on the LDS image of the times; the first write into a tile (pass A's exchange, or
+    // pass B's with tau_mode 2) follows an lds_barrier that the partner reaches only after its own fill.
+    typename std::conditional<DENSE, TimeRegInputs<S, BOTTOM>, LdsInputs<S, BOTTOM>>::type in;
+    if constexpr (DENSE) in.fill(lin);
+    else in = lin;
     RoleBc<BOTTOM> rbc;
     rbc.load(a, b);
     int tau[HS];
@@ -412,14 +446,14 @@ __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int 
             tau[j] = BOTTOM ? 16 - sg : sg;
         }
     } else {
-        path_sweep<O, S, BOTTOM, false, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+        path_sweep<O, S, BOTTOM, false, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, xchg, partner_xchg, l_skip, tau, spd, nanacc, maxdev);
         if (a.tau_mode == 1 && lane < rows) {
 #pragma unroll
             for (int j = 0; j < HS; ++j) a.tstar[(int64_t)(BOTTOM ? S - 1 - j : j) * a.B + b] = BOTTOM ? 16 - tau[j] : tau[j];
         }
     }
     spd = true;  // the reported status is the penalised solve's
-    path_sweep<O, S, BOTTOM, true, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, partner_stage, l_skip, tau, spd, nanacc, maxdev);
+    path_sweep<O, S, BOTTOM, true, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, xchg, partner_xchg, l_skip, tau, spd, nanacc, maxdev);
     // the reference's max_deviation is the maximum over ALL segments and the status covers both
     // halves: the bottom role hands its part to the top role, which writes (plain stores, and only
     // for live trajectories: a re-solve pass must leave finished trajectories untouched)
@@ -437,14 +471,23 @@ __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int 
 // One workgroup per 64-trajectory slice (path-penalty solves are not the streaming headline: no
 // persistent/prefetch structure here).  `skip` marks trajectories the re-solve loop has finished.
 template <int O, int S, bool STATUS>
-__global__ void __launch_bounds__(128) minsnap_fixed_path_kernel(GenericArgs a) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(path_dense<O, S> ? 2 : 1)))
+minsnap_fixed_path_kernel(GenericArgs a) {
     using L = FixedLds<O, S>;
     constexpr int M = 2 * O;
-    __shared__ __attribute__((aligned(16))) double lds[L::WP_DOUBLES + 64 * S + 2 * L::STAGE_DOUBLES + 17 * M + 64 + 64];
+    // DENSE (order 2, S >= 8): the staging tiles lie on top of the LDS image of the segment times (each role keeps its
+    // times in registers) and lose their padding, which brings the workgroup under 40 KB of LDS: four workgroups per
+    // CU = two waves per SIMD (the order-2 sweep fits 256 registers once its segments are separate basic blocks),
+    // and the 1024 workgroups of a 65536-trajectory batch are resident at once.
+    constexpr bool DENSE = path_dense<O, S>;
+    constexpr int TILE = 64 * path_stage_row<O, S>;
+    static_assert(L::CARRY * 64 <= TILE, "carries must fit in a staging tile");
+    static_assert(!DENSE || 64 * S <= 2 * TILE, "the image of the times must fit under the staging tiles");
+    __shared__ __attribute__((aligned(16))) double lds[L::WP_DOUBLES + (DENSE ? 0 : 64 * S) + 2 * TILE + 17 * M + 64 + 64];
     double *l_wp = lds;
     double *l_tm = l_wp + L::WP_DOUBLES;
-    double *l_stage = l_tm + 64 * S;
-    double *l_hw = l_stage + 2 * L::STAGE_DOUBLES;
+    double *l_stage = DENSE ? l_tm : l_tm + 64 * S;
+    double *l_hw = l_stage + 2 * TILE;
     double *l_dev = l_hw + 17 * M;
     int *l_skip = reinterpret_cast<int *>(l_dev + 64);
     int *l_bits = l_skip + 64;
@@ -456,6 +499,15 @@ __global__ void __launch_bounds__(128) minsnap_fixed_path_kernel(GenericArgs a) 
         // the same mask, so both leave)
         const int sk = lane < rows ? a.skip[b0 + lane] : 1;
         if (__builtin_amdgcn_ballot_w64(sk == 0) == 0) return;
+    }
+    if constexpr (DENSE) {
+        // A workgroup stores nothing before its backward sweep: started together, the resident workgroups compute with
+        // the memory system idle and then all store at once (time = compute-before-the-first-store + bytes / bandwidth:
+        // 43 us at B = 65536, S = 16).  The four workgroups of a CU (dispatch order: 256 CUs per round) start 6 S x 64
+        // clocks apart instead, so that the store phase of one overlaps the compute of the next: 40.5 us.  First
+        // round only -- later rounds are out of step by themselves -- and never for grids of <= 256 workgroups.
+        const int slot = blockIdx.x < 1024 ? (int)(blockIdx.x >> 8) : 0;
+        for (int q = 0; q < slot; ++q) __builtin_amdgcn_s_sleep(6 * S < 127 ? 6 * S : 127);
     }
     {
         const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
@@ -502,8 +554,8 @@ __global__ void __launch_bounds__(128) minsnap_fixed_path_kernel(GenericArgs a) 
     __syncthreads();
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;
-    if (role == 0) path_role<O, S, false, STATUS>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage, l_stage + L::STAGE_DOUBLES, l_skip, l_dev, l_bits);
-    else path_role<O, S, true, STATUS>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage + L::STAGE_DOUBLES, l_stage, l_skip, l_dev, l_bits);
+    if (role == 0) path_role<O, S, false, STATUS, DENSE>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage, l_stage, l_stage + TILE, l_skip, l_dev, l_bits);
+    else path_role<O, S, true, STATUS, DENSE>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage + TILE, l_stage + TILE, l_stage, l_skip, l_dev, l_bits);
 }
 
 template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream_t st) {

@@ -390,3 +390,29 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
         worst[o] = max(worst[o], float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
     print("C5 full size, 192 of 65536 trajectories vs the 80-bit oracle (norm-wise, fp32 storage):", worst)
     assert all(v < 1e-6 for v in worst.values()), worst
+
+
+@pytest.mark.parametrize("S", [8, 11, 13, 14, 15, 16])
+def test_order2_path_kernel_dense_residency(csp, S):
+    """Order 2 with the path penalty, S >= 8: the variant that shares a CU between four workgroups (staging tiles on
+    top of the LDS input image, pass B from a register copy of its inputs, staggered start of the first round).
+    Same coefficients, max_dev, status and t* picks as the generic kernel -- with and without the status outputs
+    (two kernel instantiations), for a partial last slice and for a grid of more than one resident round."""
+    import torch
+    rng = np.random.default_rng(500 + S)
+    for B, pw, outputs in ((64 * 3 + 5, 0.3, True), (64 * 3 + 5, 0.3, False), (70000 + 13, 1e-7, False), (70000 + 13, 2.0, True)):
+        wp, tm = synth.make_batch(B, S, config_id=300 + S)
+        bc = rng.normal(size=(B, 4, 3))
+        vw = rng.uniform(0.0, 0.3, size=B)
+        d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc, vw)]
+        kw = dict(order=2, path_weight=pw, vel_zero_weight_per_traj=d[3], want_status=outputs, want_max_dev=outputs)
+        r = csp.solve_batch(d[0], d[1], d[2], **kw)
+        assert r.kernel == "fixedpath_o2_s%d_f64" % S, r.kernel
+        g = csp.solve_batch(d[0], d[1], d[2], force_generic=True, **kw)
+        torch.cuda.synchronize()
+        num = (r.coeffs - g.coeffs).abs().reshape(B, -1).amax(dim=1)
+        den = g.coeffs.abs().reshape(B, -1).amax(dim=1)
+        assert float((num / den).max()) < 1e-8, (S, B, pw)
+        if outputs:
+            assert not bool(r.status.any()) and not bool(g.status.any())
+            assert float((r.max_dev - g.max_dev).abs().max()) < 1e-8 * max(1.0, float(g.max_dev.max())), (S, B)
