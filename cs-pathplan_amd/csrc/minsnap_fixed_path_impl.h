@@ -503,9 +503,10 @@ minsnap_fixed_path_kernel(GenericArgs a) {
     if constexpr (DENSE) {
         // A workgroup stores nothing before its backward sweep: started together, the resident workgroups compute with
         // the memory system idle and then all store at once (time = compute-before-the-first-store + bytes / bandwidth:
-        // 43 us at B = 65536, S = 16).  The four workgroups of a CU (dispatch order: 256 CUs per round) start 6 S x 64
-        // clocks apart instead, so that the store phase of one overlaps the compute of the next: 40.5 us.  First
-        // round only -- later rounds are out of step by themselves -- and never for grids of <= 256 workgroups.
+        // 40 us at B = 65536, S = 16).  The four workgroups of a CU (dispatch order: 256 CUs per round) start 6 S x 64
+        // clocks apart instead, so that the store phase of one overlaps the compute of the next: 37.2 us (steps of
+        // 0 / 2 S / 4 S / 6 S / 8 S x 64 clocks: 40.1 / 39.9 / 37.7 / 37.2 / 38.2 us).  First round only -- later rounds
+        // are out of step by themselves -- and never for grids of <= 256 workgroups.
         const int slot = blockIdx.x < 1024 ? (int)(blockIdx.x >> 8) : 0;
         for (int q = 0; q < slot; ++q) __builtin_amdgcn_s_sleep(6 * S < 127 ? 6 * S : 127);
     }
