@@ -358,8 +358,13 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                     *reinterpret_cast<double2 *>(stage + lane * ROW + ax * M + i) = v2;
                 }
                 if (STATUS) {
-#pragma unroll
-                    for (int i = 0; i < M; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
+                    // Non-finite values are caught on the highest-power and the constant coefficient: every endpoint
+                    // quantity of the segment (dP, the 2(o-1) scaled derivatives) enters c[0] with a non-zero Hermite
+                    // weight and T^-(2o-1), and c[M-1] is the start waypoint, so a NaN/Inf anywhere in the inputs or
+                    // the unknowns reaches one of the two.  Testing all 2o coefficients (as the plain kernel does)
+                    // keeps them live across the staging writes: 0.6 KB of scratch per lane at order 4, S >= 13.
+                    nanacc = __builtin_fma(c[0], 0.0, nanacc);
+                    nanacc = __builtin_fma(c[M - 1], 0.0, nanacc);
                 }
                 // deviation at the recorded t* (:596-617), in the local frame: P(t*) = h^T d
                 double v = __builtin_fma(l_hw[tau[j] * M + O], P1[ax], l_hw[tau[j] * M] * P0[ax]);

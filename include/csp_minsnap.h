@@ -77,7 +77,9 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 
 /* per-trajectory status bits written to `status` */
 #define CSP_TRAJ_OK 0
-#define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently) */
+#define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently);
+                                  the path-penalty kernels test the highest-power and constant coefficient of
+                                  every record, which every input and unknown of the segment enters         */
 #define CSP_TRAJ_NOT_SPD 2     /* a pivot of the free-derivative Hessian R_PP was <= 0              */
 
 typedef struct csp_minsnap_desc {
