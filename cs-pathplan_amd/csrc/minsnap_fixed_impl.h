@@ -464,8 +464,13 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 *reinterpret_cast<double2 *>(stage + row * ROW + tpos + i) = v2;
             }
             if (STATUS) {
-#pragma unroll
-                for (int i = 0; i < M; ++i) nanacc = __builtin_fma(c[i], 0.0, nanacc);
+                // Non-finite values are caught on the highest-power and the constant coefficient: every endpoint
+                // quantity of the segment (dP, the 2(o-1) scaled derivatives) enters c[0] with a non-zero weight
+                // G(0, .) (tests/test_tables.py) times T^-(2o-1), and c[M-1] is the start waypoint, so a NaN/Inf
+                // anywhere in the inputs or the unknowns reaches one of the two.  Testing all 2o coefficients kept
+                // them live across the staging writes (0.35 KB of scratch per lane at order 4, S >= 15).
+                nanacc = __builtin_fma(c[0], 0.0, nanacc);
+                nanacc = __builtin_fma(c[M - 1], 0.0, nanacc);
             }
         }
         // LDS operations of one wave execute in order, so the tile needs no barrier; the fences only

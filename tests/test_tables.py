@@ -55,6 +55,8 @@ def test_symmetries_used_by_the_fixed_kernel(o):
         assert Qt1[a][0] == -Qt1[a][o]          # a constant polynomial costs nothing
     for i in range(o):                          # high coefficient rows see positions through dP only
         assert G[i][0] == -G[i][o]
+    for a in range(1, m):                       # every endpoint quantity enters the highest-power coefficient:
+        assert G[0][a] != 0                     # the kernels' status test relies on it (recover(), `if (STATUS)`)
     for i in range(o, m):                       # low rows: c_j = start derivative j / j!
         j = m - 1 - i
         for a in range(m):
