@@ -155,7 +155,9 @@ __device__ __forceinline__ bool span_schur(const SpanView<IO> &v, double vw, dou
 using iface::IfaceLds;
 using iface::store_axis;
 
-template <int O, typename IO>
+// STATUS = the caller passed a `status` array: only then are the coefficients tested for NaN/Inf (on the values
+// as stored, so that an fp32 overflow is caught: two conversions and an fma per coefficient otherwise spent for nothing).
+template <int O, typename IO, bool STATUS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(O <= 4 ? 2 : 1)))
 minsnap_span_kernel(GenericArgs a, int lpt_log2) {
     constexpr int N = O - 1, M = 2 * O;
@@ -301,8 +303,10 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
             for (int r = 0; r < N; ++r) { a0[r] = xs[r][ax]; a1[r] = xe[r][ax]; }
             fixedk::recover<O>(P0[ax], P1[ax] - P0[ax], a0, a1, tp, ip, cc);
             store_axis<IO, M>(row + ax * M, cc);
+            if (STATUS) {
 #pragma unroll
-            for (int i = 0; i < M; ++i) nanacc = __builtin_fma((double)(IO)cc[i], 0.0, nanacc);
+                for (int i = 0; i < M; ++i) nanacc = __builtin_fma((double)(IO)cc[i], 0.0, nanacc);
+            }
         }
         l_addr[lane] = reinterpret_cast<unsigned long long>(co + (int64_t)g * (3 * M));
     };
@@ -409,7 +413,7 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
     }
     if (active) park(0, xL, xnx);   // the first segment: left end known, waypoint 1 (or the right end when c == 1) in xnx
     flush(active);
-    if (a.status && active) {
+    if (STATUS && active) {
         const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
         if (bits) atomicOr(a.status + b, bits);
     }
@@ -418,8 +422,13 @@ minsnap_span_kernel(GenericArgs a, int lpt_log2) {
 template <int O> hipError_t launch_o(const GenericArgs &a, bool f32, int lpt_log2, hipStream_t st) {
     const int64_t lanes = a.B << lpt_log2;
     const dim3 grid((unsigned)((lanes + 63) / 64)), block(64);
-    if (f32) hipLaunchKernelGGL((minsnap_span_kernel<O, float>), grid, block, 0, st, a, lpt_log2);
-    else hipLaunchKernelGGL((minsnap_span_kernel<O, double>), grid, block, 0, st, a, lpt_log2);
+    if (a.status) {
+        if (f32) hipLaunchKernelGGL((minsnap_span_kernel<O, float, true>), grid, block, 0, st, a, lpt_log2);
+        else hipLaunchKernelGGL((minsnap_span_kernel<O, double, true>), grid, block, 0, st, a, lpt_log2);
+    } else {
+        if (f32) hipLaunchKernelGGL((minsnap_span_kernel<O, float, false>), grid, block, 0, st, a, lpt_log2);
+        else hipLaunchKernelGGL((minsnap_span_kernel<O, double, false>), grid, block, 0, st, a, lpt_log2);
+    }
     return hipGetLastError();
 }
 
