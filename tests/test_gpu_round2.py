@@ -416,3 +416,32 @@ def test_order2_path_kernel_dense_residency(csp, S):
         if outputs:
             assert not bool(r.status.any()) and not bool(g.status.any())
             assert float((r.max_dev - g.max_dev).abs().max()) < 1e-8 * max(1.0, float(g.max_dev.max())), (S, B)
+
+
+@pytest.mark.parametrize("order,S", [(2, 16), (2, 6), (3, 12), (4, 16), (4, 7), (5, 8)])
+def test_status_flags_with_the_two_coefficient_test(csp, order, S):
+    """The register-resident kernels test the highest-power and the constant coefficient of every record for NaN/Inf
+    (every endpoint quantity of the segment enters the former): a zero or NaN segment time, a NaN or infinite
+    waypoint and a NaN boundary condition are flagged on exactly the trajectories that hold them -- in the first,
+    a middle and the last segment, with and without the path penalty -- like the generic kernel does."""
+    B = 200
+    wp, tm = synth.make_batch(B, S, config_id=40 + order)
+    bc = np.zeros((B, 4, 3))
+    tm[5, 0] = 0.0
+    tm[17, S // 2] = float("nan")
+    tm[64, S - 1] = 0.0
+    wp[70, 0, 1] = float("nan")
+    wp[99, S // 2, 2] = float("inf")
+    wp[130, S, 0] = float("nan")
+    bc[150, 0, 0] = float("nan")
+    bc[199, 1, 2] = float("nan")
+    bad = [5, 17, 64, 70, 99, 130, 150, 199]
+    for pw in ((0.0, 0.3) if order <= 4 else (0.0,)):
+        for force in (False, True):
+            r = csp.solve_batch(wp, tm, bc, order=order, path_weight=pw, want_status=True, force_generic=force)
+            if not force:
+                assert r.kernel.startswith("fixedpath_" if pw else "fixed_"), r.kernel
+            flagged = np.flatnonzero(r.status & 1).tolist()
+            assert flagged == bad, (order, S, pw, r.kernel, flagged)
+            good = np.setdiff1d(np.arange(B), bad)
+            assert np.isfinite(r.coeffs[good]).all()
