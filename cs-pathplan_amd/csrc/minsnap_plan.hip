@@ -6,6 +6,8 @@
 //     rule and the climb-rate / turn-radius statistics (:97-195).
 // The loop bookkeeping is one lane per trajectory; sampling runs one lane per (trajectory, segment)
 // for trajectories of up to 64 segments and one lane per trajectory beyond.
+#include <mutex>
+
 #include "minsnap_launch.h"
 
 namespace csp {
@@ -567,8 +569,20 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
 // end-point rule and the statistics are applied after the runs have been placed (sample_place_kernel,
 // sample_stats_kernel).  Same accumulated candidate times, same squared-distance test, same chain: the recorded
 // samples are bitwise those of the other samplers.
+// Candidate times are ACCUMULATED (t += dt, minimum_snap.cpp:136) and their rounding decides which candidates exist
+// and where they lie, so a wave that wants 64 of them at once has to run the 63 dependent additions every round -- a
+// third of this kernel's time for a flight of six 60-second legs.  With dt = 0.1 (every segment of >= 1 s) the sequence
+// is the same for every segment of every call: `tacc[k]` = the (k+1)-th accumulated time, built once per device by one
+// lane doing the additions in order (tacc_init_kernel), turns the 63 additions into one coalesced load.
+constexpr int TACC_N = 8192;   // candidates per segment covered by the table (819 s of flight per segment)
+__global__ void tacc_init_kernel(double *tab, int n) {
+    double t = 0.1;
+    for (int k = 0; k < n; ++k) { tab[k] = t; t += 0.1; }
+}
+
 template <int O>
-__global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts) {
+__global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
+                                                             const double *tacc) {
     constexpr int M = 2 * O;
     __shared__ double lc[3 * 64];
     const int lane = threadIdx.x;
@@ -608,11 +622,20 @@ __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, doubl
     }
     bool dense = false;
     double tb = dt;
+    const bool use_tab = tacc != nullptr && dt == 0.1;
+    int k0 = 0;                                   // index of tb in the accumulated sequence
+    double t_pref = use_tab ? tacc[lane] : 0.0;
     while (tb <= t_end(T)) {
         double t = tb;
-        for (int i = 0; i < 63; ++i) {
-            if (lane > i) t += dt;
+        if (use_tab && k0 + 64 <= TACC_N) {
+            t = t_pref;
+        } else {
+            for (int i = 0; i < 63; ++i) {
+                if (lane > i) t += dt;
+            }
         }
+        k0 += 64;
+        if (use_tab && k0 + 64 <= TACC_N) t_pref = tacc[k0 + lane];   // the next round's times, in flight during this round
         const double run = bcast(t, 63) + dt;
         const bool exists = t <= t_end(T);
         double cur[3];
@@ -722,16 +745,34 @@ __global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const do
     }
 }
 
+// The per-device table of accumulated candidate times (64 KB, built at the first call, kept for the life of the process).
+static const double *tacc_table(hipStream_t st) {
+    struct Slot { std::once_flag once; double *tab = nullptr; };
+    static Slot slots[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Slot &sl = slots[dev];
+    std::call_once(sl.once, [&] {
+        double *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(double) * TACC_N) != hipSuccess) { (void)hipGetLastError(); return; }
+        hipLaunchKernelGGL(tacc_init_kernel, dim3(1), dim3(1), 0, st, p, TACC_N);
+        if (hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess) sl.tab = p;
+        else (void)hipFree(p);
+    });
+    return sl.tab;   // null = the kernels accumulate by themselves
+}
+
 hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
                                        int64_t total_segments, hipStream_t st) {
     if (a.B == 0 || total_segments == 0) return hipSuccess;
     const dim3 grid((unsigned)total_segments), block(64);
+    const double *tacc = tacc_table(st);
     switch (a.order) {
-        case 1: hipLaunchKernelGGL((sample_wave_seg_kernel<1>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
-        case 2: hipLaunchKernelGGL((sample_wave_seg_kernel<2>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
-        case 3: hipLaunchKernelGGL((sample_wave_seg_kernel<3>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
-        case 4: hipLaunchKernelGGL((sample_wave_seg_kernel<4>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
-        case 5: hipLaunchKernelGGL((sample_wave_seg_kernel<5>), grid, block, 0, st, a, tmp, tmp_off, seg_counts); break;
+        case 1: hipLaunchKernelGGL((sample_wave_seg_kernel<1>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
+        case 2: hipLaunchKernelGGL((sample_wave_seg_kernel<2>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
+        case 3: hipLaunchKernelGGL((sample_wave_seg_kernel<3>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
+        case 4: hipLaunchKernelGGL((sample_wave_seg_kernel<4>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
+        case 5: hipLaunchKernelGGL((sample_wave_seg_kernel<5>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), block, 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);

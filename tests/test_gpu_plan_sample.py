@@ -161,6 +161,27 @@ def test_wave_cooperative_sampler_for_long_legs(csp, oracle_mod, order, scale, v
         assert int(r[1][3]) >= 1
 
 
+def test_segment_wave_sampler_time_table_edges(csp):
+    """The per-segment wave sampler of the host path reads accumulated candidate times from a per-device table when
+    dt = 0.1 (minsnap_plan.hip: tacc).  Edges: a segment longer than the table (9000 candidates > 8192), a segment with
+    dt = T/10 != 0.1 (no table), ordinary ones -- bitwise the sequential sampler."""
+    import torch
+    wp = np.array([[[0.0, 0.0, 0.0], [4500.0, 10.0, 0.0], [4502.5, 10.0, 1.0], [4652.5, -20.0, 0.0], [4800.0, 0.0, 5.0]],
+                   [[10.0, 0.0, 0.0], [400.0, 50.0, 0.0], [401.0, 50.0, 0.0], [1000.0, 0.0, 9.0], [5200.0, 100.0, 0.0]]])
+    for order in (2, 4):
+        plan = csp.plan_batch(torch.from_numpy(wp).cuda(), 5.0, 0.1, order=order)
+        tm = plan.times.cpu().numpy()
+        assert tm.max() / 0.1 > 8192 + 64 and tm.min() < 1.0
+        cap = 1 << 15
+        o = csp.sample_batch(plan.times, plan.coeffs, 3.0, cap, one_lane=True)
+        torch.cuda.synchronize()
+        h = csp.sample_batch(tm, plan.coeffs.cpu().numpy(), 3.0, cap)     # host path: one wave per segment
+        assert np.array_equal(h[1], o[1].cpu().numpy()), (order, h[1], o[1])
+        for b in range(2):
+            assert np.array_equal(h[0][b, :h[1][b]], o[0][b, :h[1][b]].cpu().numpy()), (order, b)
+        assert np.array_equal(h[2], o[2].cpu().numpy())
+
+
 def test_ragged_sampling_equals_per_trajectory_sampling(csp):
     """Ragged batches (seg_offsets) through all three samplers: trajectory b of the ragged call must be
     bitwise the uniform single-trajectory call."""
