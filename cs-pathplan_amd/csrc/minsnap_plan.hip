@@ -384,6 +384,17 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
     if (lane == 0) { stats[b * 2] = max_climb; stats[b * 2 + 1] = min_r; }
 }
 
+// Candidate times are ACCUMULATED (t += dt, minimum_snap.cpp:136) and their rounding decides which candidates exist
+// and where they lie, so a wave that wants 64 of them at once has to run the 63 dependent additions every round -- a
+// third of this kernel's time for a flight of six 60-second legs.  With dt = 0.1 (every segment of >= 1 s) the sequence
+// is the same for every segment of every call: `tacc[k]` = the (k+1)-th accumulated time, built once per device by one
+// lane doing the additions in order (tacc_init_kernel), turns the 63 additions into one coalesced load.
+constexpr int TACC_N = 8192;   // candidates per segment covered by the table (819 s of flight per segment)
+__global__ void tacc_init_kernel(double *tab, int n) {
+    double t = 0.1;
+    for (int k = 0; k < n; ++k) { tab[k] = t; t += 0.1; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-cooperative sampler for LONG segments (hundreds to thousands of candidates each: kilometre
 // legs sampled every 0.1 s, the reference's own use -- one flight per call).  One wave per
@@ -402,7 +413,7 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
 // Same power sums, squared-distance test and statistics formulas as the other two samplers:
 // identical samples, counts and statistics.
 template <int O, typename IO>
-__global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
+__global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a, const double *tacc) {
     constexpr int M = 2 * O;
     __shared__ double ring[130 * 3];  // [0],[1]: the two samples before the queued batch; [2..129]: the batch (<= 127)
     __shared__ double lc[3 * 64];     // the window's candidates, for the successor look-ahead
@@ -466,13 +477,23 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
         eval_poly<M>(c, 0.0, prev);
         if (n == 0) record(prev);
         double tb = dt;   // accumulated time of the window's first candidate
+        const bool use_tab = tacc != nullptr && dt == 0.1;
+        int k0 = 0;       // index of tb in the accumulated sequence
+        double t_pref = use_tab ? tacc[lane] : 0.0;
         while (tb <= t_end(T)) {
             // the window's 64 candidate times: lane L performs the first L of the 63 sequential additions
-            // (the same partial sums, in the same order, as the reference's running t)
+            // (the same partial sums, in the same order, as the reference's running t) -- or reads them from the
+            // table of those sums when dt = 0.1
             double t = tb;
-            for (int i = 0; i < 63; ++i) {
-                if (lane > i) t += dt;
+            if (use_tab && k0 + 64 <= TACC_N) {
+                t = t_pref;
+            } else {
+                for (int i = 0; i < 63; ++i) {
+                    if (lane > i) t += dt;
+                }
             }
+            k0 += 64;
+            if (use_tab && k0 + 64 <= TACC_N) t_pref = tacc[k0 + lane];
             const double run = bcast(t, 63) + dt;   // the accumulated time of the next window's first candidate
             const bool exists = t <= t_end(T);
             double cur[3];
@@ -569,17 +590,6 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a) {
 // end-point rule and the statistics are applied after the runs have been placed (sample_place_kernel,
 // sample_stats_kernel).  Same accumulated candidate times, same squared-distance test, same chain: the recorded
 // samples are bitwise those of the other samplers.
-// Candidate times are ACCUMULATED (t += dt, minimum_snap.cpp:136) and their rounding decides which candidates exist
-// and where they lie, so a wave that wants 64 of them at once has to run the 63 dependent additions every round -- a
-// third of this kernel's time for a flight of six 60-second legs.  With dt = 0.1 (every segment of >= 1 s) the sequence
-// is the same for every segment of every call: `tacc[k]` = the (k+1)-th accumulated time, built once per device by one
-// lane doing the additions in order (tacc_init_kernel), turns the 63 additions into one coalesced load.
-constexpr int TACC_N = 8192;   // candidates per segment covered by the table (819 s of flight per segment)
-__global__ void tacc_init_kernel(double *tab, int n) {
-    double t = 0.1;
-    for (int k = 0; k < n; ++k) { tab[k] = t; t += 0.1; }
-}
-
 template <int O>
 __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
                                                              const double *tacc) {
@@ -785,12 +795,13 @@ hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const i
 template <typename IO> static hipError_t launch_sample_t(const SampleArgs &a, hipStream_t st) {
     if (a.long_segments && !a.one_lane) {   // one wave per trajectory, 64 candidates per round
         const dim3 grid((unsigned)a.B), block(64);
+        const double *tacc = tacc_table(st);
         switch (a.order) {
-            case 1: hipLaunchKernelGGL((sample_wave_kernel<1, IO>), grid, block, 0, st, a); break;
-            case 2: hipLaunchKernelGGL((sample_wave_kernel<2, IO>), grid, block, 0, st, a); break;
-            case 3: hipLaunchKernelGGL((sample_wave_kernel<3, IO>), grid, block, 0, st, a); break;
-            case 4: hipLaunchKernelGGL((sample_wave_kernel<4, IO>), grid, block, 0, st, a); break;
-            case 5: hipLaunchKernelGGL((sample_wave_kernel<5, IO>), grid, block, 0, st, a); break;
+            case 1: hipLaunchKernelGGL((sample_wave_kernel<1, IO>), grid, block, 0, st, a, tacc); break;
+            case 2: hipLaunchKernelGGL((sample_wave_kernel<2, IO>), grid, block, 0, st, a, tacc); break;
+            case 3: hipLaunchKernelGGL((sample_wave_kernel<3, IO>), grid, block, 0, st, a, tacc); break;
+            case 4: hipLaunchKernelGGL((sample_wave_kernel<4, IO>), grid, block, 0, st, a, tacc); break;
+            case 5: hipLaunchKernelGGL((sample_wave_kernel<5, IO>), grid, block, 0, st, a, tacc); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

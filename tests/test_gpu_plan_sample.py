@@ -174,7 +174,9 @@ def test_segment_wave_sampler_time_table_edges(csp):
         assert tm.max() / 0.1 > 8192 + 64 and tm.min() < 1.0
         cap = 1 << 15
         o = csp.sample_batch(plan.times, plan.coeffs, 3.0, cap, one_lane=True)
+        w = csp.sample_batch(plan.times, plan.coeffs, 3.0, cap, long_segments=True)   # one wave per trajectory, same table
         torch.cuda.synchronize()
+        assert torch.equal(w[1], o[1]) and torch.equal(w[0], o[0]) and torch.equal(w[2], o[2])
         h = csp.sample_batch(tm, plan.coeffs.cpu().numpy(), 3.0, cap)     # host path: one wave per segment
         assert np.array_equal(h[1], o[1].cpu().numpy()), (order, h[1], o[1])
         for b in range(2):
