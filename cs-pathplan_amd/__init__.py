@@ -41,6 +41,7 @@ TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
 EXPORTED_SYMBOLS = (
     "csp_minsnap_solve_batch", "csp_minsnap_solve_batch_sharded", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
+    "csp_minsnap_generate_batch", "csp_minsnap_sample_capacity",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
     "csp_minsnap_strerror", "csp_minsnap_last_hip_error", "csp_minsnap_release_cached_memory",
     "csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch",
@@ -93,6 +94,11 @@ _lib.csp_minsnap_plan_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_sample_batch.restype = ctypes.c_int
 _lib.csp_minsnap_sample_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+_lib.csp_minsnap_generate_batch.restype = ctypes.c_int
+_lib.csp_minsnap_generate_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                            ctypes.c_double, ctypes.c_int64] + [ctypes.c_void_p] * 10 + [ctypes.c_size_t, ctypes.c_void_p]
+_lib.csp_minsnap_sample_capacity.restype = ctypes.c_int64
+_lib.csp_minsnap_sample_capacity.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
 for _n in ("csp_geo_wgs84_to_enu_batch", "csp_geo_enu_to_wgs84_batch"):
     getattr(_lib, _n).restype = ctypes.c_int
     getattr(_lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
@@ -437,6 +443,87 @@ def plan_batch(waypoints, v_avg, min_time_s, bc=None, order=3, path_weight=0.0, 
                                        bc.ctypes.data, r.times.ctypes.data, r.coeffs.ctypes.data, r.max_dev.ctypes.data,
                                        r.vel_zero_weight.ctypes.data, r.iterations.ctypes.data, r.status.ctypes.data,
                                        None, 0, None))
+    return r
+
+
+def sample_capacity(waypoints, v_avg, min_time_s, order=3):
+    """Upper bound of the samples per trajectory (csp_minsnap_sample_capacity), from host waypoints [B,S+1,3]."""
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    waypoints = np.ascontiguousarray(waypoints, dtype=_np_dtype(dtype))
+    desc = make_desc(order, waypoints.shape[0], waypoints.shape[1] - 1, dtype, mem_space=MEM_HOST)
+    cap = int(_lib.csp_minsnap_sample_capacity(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg), float(min_time_s)))
+    if cap < 0:
+        raise CspError(-1, "csp_minsnap_sample_capacity")
+    return cap
+
+
+class Generated(Plan):
+    """Plan + samples [B,capacity,3], counts [B], stats [B,2]."""
+    __slots__ = ("samples", "counts", "stats")
+
+
+def generate_batch(waypoints, v_avg, min_time_s, sample_distance, capacity=None, bc=None, order=3, path_weight=0.0,
+                   vel_zero_weight=0.0, long_segments=False):
+    """The whole of GenerateTrajectoryMatrix (math_util/minimum_snap.cpp:22-206) in one call
+    (csp_minsnap_generate_batch = plan_batch + sample_batch, bit for bit).  Uniform batches, numpy (host: one upload,
+    one download, one synchronisation) or torch CUDA tensors (asynchronous; `capacity` required)."""
+    on_device = _is_torch(waypoints)
+    m = 2 * int(order)
+    r = Generated()
+    flags = FLAG_LONG_SEGMENTS if long_segments else 0
+    if on_device:
+        import torch
+        if capacity is None:
+            raise ValueError("device-memory generate_batch needs a capacity")
+        dev, tdt = waypoints.device, waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        waypoints = waypoints.contiguous()
+        B, S = waypoints.shape[0], waypoints.shape[1] - 1
+        bc = torch.zeros((1, 4, 3), dtype=tdt, device=dev) if bc is None else bc.to(tdt).contiguous().reshape(-1, 4, 3)
+        r.times = torch.empty((B, S), dtype=tdt, device=dev)
+        r.coeffs = torch.empty((B, S, 3, m), dtype=tdt, device=dev)
+        r.max_dev = torch.empty(B, dtype=torch.float64, device=dev)
+        r.vel_zero_weight = torch.empty(B, dtype=torch.float64, device=dev)
+        r.iterations = torch.empty(B, dtype=torch.int32, device=dev)
+        r.status = torch.empty(B, dtype=torch.int32, device=dev)
+        r.samples = torch.zeros((B, capacity, 3), dtype=tdt, device=dev)
+        r.counts = torch.empty(B, dtype=torch.int32, device=dev)
+        r.stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
+        desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_DEVICE, bc.shape[0] == B and B != 1,
+                         device_id=dev.index if dev.index is not None else -1, flags=flags)
+        need = int(_lib.csp_minsnap_plan_workspace_bytes(ctypes.byref(desc)))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _check(_lib.csp_minsnap_generate_batch(ctypes.byref(desc), waypoints.data_ptr(), float(v_avg), float(min_time_s), bc.data_ptr(),
+                                               float(sample_distance), int(capacity), r.samples.data_ptr(), r.counts.data_ptr(),
+                                               r.stats.data_ptr(), r.times.data_ptr(), r.coeffs.data_ptr(), r.max_dev.data_ptr(),
+                                               r.vel_zero_weight.data_ptr(), r.iterations.data_ptr(), r.status.data_ptr(),
+                                               ws.data_ptr(), need, ctypes.c_void_p(st)))
+        return r
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    waypoints = np.ascontiguousarray(waypoints, dtype=npdt)
+    B, S = waypoints.shape[0], waypoints.shape[1] - 1
+    bc = np.zeros((1, 4, 3), dtype=npdt) if bc is None else np.ascontiguousarray(bc, dtype=npdt).reshape(-1, 4, 3)
+    desc = make_desc(order, B, S, dtype, path_weight, vel_zero_weight, MEM_HOST, bc.shape[0] == B and B != 1, flags=flags)
+    if capacity is None:
+        capacity = int(_lib.csp_minsnap_sample_capacity(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg), float(min_time_s)))
+    r.times = np.empty((B, S), dtype=npdt)
+    r.coeffs = np.empty((B, S, 3, m), dtype=npdt)
+    r.max_dev = np.empty(B, dtype=np.float64)
+    r.vel_zero_weight = np.empty(B, dtype=np.float64)
+    r.iterations = np.empty(B, dtype=np.int32)
+    r.status = np.empty(B, dtype=np.int32)
+    r.samples = np.zeros((B, capacity, 3), dtype=npdt)
+    r.counts = np.empty(B, dtype=np.int32)
+    r.stats = np.empty((B, 2), dtype=np.float64)
+    _check(_lib.csp_minsnap_generate_batch(ctypes.byref(desc), waypoints.ctypes.data, float(v_avg), float(min_time_s), bc.ctypes.data,
+                                           float(sample_distance), int(capacity), r.samples.ctypes.data, r.counts.ctypes.data,
+                                           r.stats.ctypes.data, r.times.ctypes.data, r.coeffs.ctypes.data, r.max_dev.ctypes.data,
+                                           r.vel_zero_weight.ctypes.data, r.iterations.ctypes.data, r.status.ctypes.data,
+                                           None, 0, None))
     return r
 
 

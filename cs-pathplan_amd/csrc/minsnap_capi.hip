@@ -545,6 +545,7 @@ int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, 
     if (rc != CSP_OK) return rc;
     CSP_HIP(hc.download());
     if (raised != 0) {
+        hc.touch();
         rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
                          hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true, 2,
                          hc.ptr<int32_t>(o_pd));
@@ -648,6 +649,175 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
         return CSP_OK;
     }
     CSP_HIP(hc.download());
+    return CSP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Host-side estimate of the segment times (minimum_snap.cpp:59-72) for SIZING only: the device computes them again
+// (possibly an ulp away: fused multiply-adds), so every count derived from these carries slack.
+void estimate_times(const csp_minsnap_desc *desc, const Shape &s, const void *waypoints, double v_avg, double min_time_s,
+                    std::vector<double> &T) {
+    const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    T.resize((size_t)total_seg);
+    int64_t g = 0;
+    for (int64_t b = 0; b < s.B; ++b) {
+        const int64_t nseg = s.ragged ? desc->seg_offsets[b + 1] - desc->seg_offsets[b] : s.S;
+        for (int64_t k = 0; k < nseg; ++k, ++g) {
+            double p[6];
+            for (int q = 0; q < 6; ++q)
+                p[q] = s.f32 ? (double)((const float *)waypoints)[(g + b) * 3 + q] : ((const double *)waypoints)[(g + b) * 3 + q];
+            const double dx = p[3] - p[0], dy = p[4] - p[1], dz = p[5] - p[2];
+            double t = v_avg > 1e-6 ? std::sqrt(dx * dx + dy * dy + dz * dz) / v_avg : min_time_s;
+            if (t < min_time_s) t = min_time_s;
+            T[(size_t)g] = t;
+        }
+    }
+}
+
+// Candidates of one segment (:126-136), generously: the device's time may differ in its last bits
+int64_t candidate_bound(double T, bool f32) {
+    if (!(T >= 1.0e-15 && T <= 1.1e7)) return 0;   // the device emits none outside [1e-14, 1e7] (minsnap_plan.hip t_end)
+    const double Tw = T * (1.0 + (f32 ? 1e-6 : 1e-12));
+    const double dt = T / 10.0 < 0.1 ? T / 10.0 : 0.1;
+    return (int64_t)((Tw + 1e-12) / (dt * (1.0 - (f32 ? 1e-6 : 1e-12)))) + 2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t csp_minsnap_sample_capacity(const csp_minsnap_desc *desc, const void *waypoints_host, double v_avg, double min_time_s) {
+    Shape s;
+    if (validate(desc, s) != CSP_OK || !waypoints_host) return -1;
+    std::vector<double> T;
+    estimate_times(desc, s, waypoints_host, v_avg, min_time_s, T);
+    int64_t cap = 2, g = 0;
+    for (int64_t b = 0; b < s.B; ++b) {
+        const int64_t nseg = s.ragged ? desc->seg_offsets[b + 1] - desc->seg_offsets[b] : s.S;
+        int64_t traj = 2;
+        for (int64_t k = 0; k < nseg; ++k, ++g) traj += candidate_bound(T[(size_t)g], s.f32);
+        if (traj > cap) cap = traj;
+    }
+    return cap;
+}
+
+int csp_minsnap_generate_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
+                               const void *bc, double sample_distance, int64_t capacity, void *samples,
+                               int32_t *counts, double *stats, void *times, void *coeffs, double *max_dev,
+                               double *vel_zero_weight_out, int32_t *iterations, int32_t *status,
+                               void *workspace, size_t workspace_bytes, void *hip_stream) {
+    Shape s;
+    int rc = validate(desc, s);
+    if (rc != CSP_OK) return rc;
+    if (s.B == 0) return CSP_OK;
+    if (!waypoints || !bc || !samples || !counts || capacity < 1) return CSP_ERR_INVALID_ARG;
+    if (desc->flags & CSP_FLAG_SEGMENT_MAJOR) return CSP_ERR_INVALID_ARG;   // the plan call has no segment-major form
+    rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    csp::SampleArgs a;
+    a.B = s.B; a.S = s.S; a.order = s.order; a.capacity = capacity; a.sample_distance = sample_distance;
+    a.keep_dist2 = keep_threshold(sample_distance);
+    a.seg_major = 0;
+    a.Smax = s.Smax;
+    a.one_lane = (desc->flags & CSP_FLAG_FORCE_GENERIC) ? 1 : 0;
+    a.long_segments = (desc->flags & CSP_FLAG_LONG_SEGMENTS) ? 1 : 0;
+    if (desc->mem_space == CSP_MEM_DEVICE) {
+        if (!times || !coeffs) return CSP_ERR_INVALID_ARG;
+        rc = plan_device(desc, s, waypoints, v_avg, min_time_s, bc, times, coeffs, max_dev, vel_zero_weight_out, iterations,
+                         status, workspace, workspace_bytes, st, false);
+        if (rc != CSP_OK) return rc;
+        a.times = times; a.coeffs = coeffs; a.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+        a.samples = samples; a.counts = counts; a.stats = stats;
+        hipError_t e = csp::launch_sample(a, s.f32, st);
+        return e == hipSuccess ? CSP_OK : hip_fail(e, "sample launch");
+    }
+
+    // CSP_MEM_HOST: one arena, one upload, [time allocation, first solve, loop bookkeeping, sampling], one download
+    const int64_t total_seg = s.ragged ? desc->seg_offsets[s.B] : s.B * (int64_t)s.S;
+    std::vector<double> Test;
+    estimate_times(desc, s, waypoints, v_avg, min_time_s, Test);
+    if (!a.long_segments && total_seg > 0) {   // as csp_minsnap_sample_batch decides from host-resident times
+        double cand = 0.0;
+        for (double T : Test) cand += (T > 1.0 && T < 1e12) ? T * 10.0 : 10.0;
+        a.long_segments = cand > 128.0 * (double)total_seg;
+    }
+    std::vector<int64_t> run_off;   // per-segment runs of the one-wave-per-segment sampler (see csp_minsnap_sample_batch)
+    if (a.long_segments && !a.one_lane && !s.f32 && s.B <= 64 && total_seg >= 2) {
+        run_off.resize((size_t)total_seg + 1);
+        run_off[0] = 0;
+        bool fits = true;
+        int64_t g = 0;
+        for (int64_t b = 0; b < s.B && fits; ++b) {
+            const int64_t nseg = s.ragged ? desc->seg_offsets[b + 1] - desc->seg_offsets[b] : s.S;
+            int64_t traj = 2;
+            for (int64_t k = 0; k < nseg; ++k, ++g) {
+                const int64_t cand = candidate_bound(Test[(size_t)g], false);
+                run_off[(size_t)g + 1] = run_off[(size_t)g] + cand + 3;   // + first sample, + the parked end point, + slack
+                traj += cand;
+            }
+            fits = traj <= capacity;
+        }
+        if (!fits) run_off.clear();
+    }
+    const size_t m = 2 * (size_t)s.order;
+    const size_t n_wp = (size_t)(total_seg + s.B) * 3 * s.elt, n_tm = (size_t)total_seg * s.elt;
+    const size_t n_bc = (size_t)(desc->bc_per_trajectory ? s.B : 1) * 12 * s.elt, n_co = (size_t)total_seg * 3 * m * s.elt;
+    const size_t n_sm = (size_t)s.B * (size_t)capacity * 3 * s.elt;
+    csp_minsnap_desc dd = *desc;
+    dd.mem_space = CSP_MEM_DEVICE;
+    const size_t n_ws = csp_minsnap_plan_workspace_bytes(&dd);
+    // one flight with a large `capacity` (an upper bound: every candidate): beyond 1 MB only the rows in use come back
+    const bool two_step = s.B == 1 && n_sm > ((size_t)1 << 20);
+    csp::HostCall hc(current_device(), st);
+    const size_t o_wp = hc.in(waypoints, n_wp), o_bc = hc.in(bc, n_bc);
+    const size_t o_so = s.ragged ? hc.in(desc->seg_offsets, (size_t)(s.B + 1) * 8) : 0;
+    const size_t o_vi = desc->vel_zero_weight_per_traj ? hc.in(desc->vel_zero_weight_per_traj, (size_t)s.B * 8) : 0;
+    const size_t o_ro = !run_off.empty() ? hc.in(run_off.data(), run_off.size() * 8) : 0;
+    int32_t raised = 0;
+    const size_t o_ct = hc.out(counts, (size_t)s.B * 4), o_sx = hc.out(stats, (size_t)s.B * 16), o_pd = hc.out(&raised, 4);
+    const size_t o_md = hc.out(max_dev, (size_t)s.B * 8), o_vw = hc.out(vel_zero_weight_out, (size_t)s.B * 8);
+    const size_t o_it = hc.out(iterations, (size_t)s.B * 4), o_st = hc.out(status, (size_t)s.B * 4);
+    const size_t o_sm_out = two_step ? 0 : hc.out(samples, n_sm);
+    const size_t o_tm_out = times ? hc.out(times, n_tm) : 0, o_co_out = coeffs ? hc.out(coeffs, n_co) : 0;
+    const size_t o_sm = two_step ? hc.scratch(n_sm) : o_sm_out;
+    const size_t o_tm = times ? o_tm_out : hc.scratch(n_tm), o_co = coeffs ? o_co_out : hc.scratch(n_co);
+    const size_t o_ws = hc.scratch(n_ws);
+    const size_t o_tmp = !run_off.empty() ? hc.scratch((size_t)run_off.back() * 24) : 0;
+    const size_t o_sc = !run_off.empty() ? hc.scratch((size_t)total_seg * 4) : 0;
+    CSP_HIP(hc.upload());
+    if (s.ragged) dd.seg_offsets = hc.ptr<const int64_t>(o_so);
+    dd.vel_zero_weight_per_traj = desc->vel_zero_weight_per_traj ? hc.ptr<const double>(o_vi) : nullptr;
+    a.times = hc.ptr(o_tm); a.coeffs = hc.ptr(o_co); a.seg_off = s.ragged ? hc.ptr<const int64_t>(o_so) : nullptr;
+    a.samples = hc.ptr(o_sm); a.counts = hc.ptr<int32_t>(o_ct); a.stats = hc.ptr<double>(o_sx);
+    const bool loop = desc->path_weight > 0.0;
+    for (int round = 0; round < 2; ++round) {
+        // round 0: time allocation + first solve (+ bookkeeping); round 1 (only if somebody's weight was raised): the
+        // remaining <= 10 passes, checked one by one.  Sampling and ONE copy back follow either.
+        if (round) hc.touch();
+        rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
+                         hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true,
+                         loop ? round + 1 : 0, loop ? hc.ptr<int32_t>(o_pd) : nullptr);
+        if (rc != CSP_OK) return rc;
+        hipError_t e;
+        if (!run_off.empty())
+            e = csp::launch_sample_segment_waves(a, hc.ptr<double>(o_tmp), hc.ptr<const int64_t>(o_ro), hc.ptr<int32_t>(o_sc), total_seg, st);
+        else
+            e = csp::launch_sample(a, s.f32, st);
+        if (e != hipSuccess) return hip_fail(e, "sample launch");
+        CSP_HIP(hc.download());
+        if (!loop || raised == 0) break;
+    }
+    if (two_step) {
+        const int64_t rows = counts[0] < capacity ? (counts[0] > 0 ? counts[0] : 0) : capacity;
+        if (rows) {
+            CSP_HIP(hipMemcpyAsync(samples, hc.ptr(o_sm), (size_t)rows * 3 * s.elt, hipMemcpyDeviceToHost, st));
+            CSP_HIP(hipStreamSynchronize(st));
+        }
+    }
     return CSP_OK;
 }
 

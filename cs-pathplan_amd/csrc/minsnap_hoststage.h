@@ -151,6 +151,9 @@ public:
         return hipSuccess;
     }
 
+    // More device work follows a download() (second round of a call): the arena is busy again until the next download().
+    void touch() { dirty_ = true; }
+
     // Copies every out() buffer back and synchronises the stream.
     hipError_t download() {
         hipError_t e;

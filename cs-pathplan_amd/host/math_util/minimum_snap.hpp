@@ -5,9 +5,9 @@
 //
 // Everything numeric goes through the C-ABI (include/csp_minsnap.h) to the HIP kernels: there is
 // no host solver, sampler or time allocation in here.  SolveQPClosedForm -> csp_minsnap_solve_batch;
-// GenerateTrajectoryMatrix -> csp_minsnap_plan_batch (time allocation + the <=10x re-solve loop,
-// minimum_snap.cpp:59-90) then csp_minsnap_sample_batch (sampling / distance thinning / statistics,
-// :97-205).  The host only marshals matrices.
+// GenerateTrajectoryMatrix -> csp_minsnap_generate_batch (time allocation + the <=10x re-solve loop,
+// minimum_snap.cpp:59-90, then sampling / distance thinning / statistics, :97-205, in one call).
+// The host only marshals matrices.
 //
 // Matrix types: real Eigen when <Eigen/Dense> exists (then the signatures are the reference's,
 // token for token), otherwise the bundled csp_host mini types (same member names).
@@ -136,8 +136,7 @@ public:
             return MatrixXd();
         }
         const int S = (int)Path.rows() - 1;
-        const int m = 2 * order;
-        std::vector<double> wp((size_t)(S + 1) * 3), bc(12), tm((size_t)S), co((size_t)S * 3 * m);
+        std::vector<double> wp((size_t)(S + 1) * 3), bc(12);
         for (int i = 0; i <= S; ++i)
             for (int a = 0; a < 3; ++a) wp[(size_t)i * 3 + a] = Path(i, a);
         for (int a = 0; a < 3; ++a) {
@@ -155,12 +154,18 @@ public:
         d.vel_zero_weight = vel_zero_weight;
         d.mem_space = CSP_MEM_HOST;
         d.device_id = -1;
-        // time allocation (:63-72) + re-solve loop (:80-90) on the device
+        // the whole routine in ONE call: time allocation (:63-72), re-solve loop (:80-90), sampling, thinning and statistics
+        // (:97-195); capacity = every evaluation point (degenerate / absurd segment times get no candidates on the device)
+        const int64_t cap = csp_minsnap_sample_capacity(&d, wp.data(), V_avg, min_time_s);
+        if (cap < 1) { last_status = CSP_ERR_INVALID_ARG; return MatrixXd(); }
+        std::vector<double> samples((size_t)cap * 3);
+        int32_t count = 0, iters = 0;
+        double stats[2] = {0.0, 1.0e12};
         double max_dev = 0.0, vw_final = vel_zero_weight;
-        int32_t iters = 0;
-        last_status = csp_minsnap_plan_batch(&d, wp.data(), V_avg, min_time_s, bc.data(), tm.data(), co.data(),
-                                             &max_dev, &vw_final, &iters, nullptr, nullptr, 0, nullptr);
-        if (last_status != CSP_OK) {
+        last_status = csp_minsnap_generate_batch(&d, wp.data(), V_avg, min_time_s, bc.data(), sample_distance, cap, samples.data(),
+                                                 &count, stats, nullptr, nullptr, &max_dev, &vw_final, &iters, nullptr, nullptr, 0,
+                                                 nullptr);
+        if (last_status != CSP_OK || count > cap) {
             std::cerr << "TrajectoryGeneratorTool::GenerateTrajectoryMatrix: " << csp_minsnap_strerror(last_status)
                       << " " << csp_minsnap_last_hip_error() << std::endl;
             return MatrixXd();
@@ -168,24 +173,6 @@ public:
         last_vel_zero_weight = vw_final;
         last_iterations = iters;
         if (verbose && iters > 0) std::cout << "vel_zero_weight increased " << iters << "x to " << vw_final << " (max_dev=" << max_dev << ")" << std::endl;
-        // sampling, thinning and statistics (:97-195) on the device; capacity = every evaluation point
-        int64_t cap = 2;
-        for (int i = 0; i < S; ++i) {
-            const double T = tm[(size_t)i];
-            cap += 2;
-            // degenerate / absurd segment times get no candidates on the device (minsnap_plan.hip t_end)
-            if (!(T >= 1.0e-14 && T <= 1.0e7)) continue;
-            const double dt = T / 10.0 < 0.1 ? T / 10.0 : 0.1;
-            cap += (int64_t)((T + 1e-12) / dt);
-        }
-        std::vector<double> samples((size_t)cap * 3);
-        int32_t count = 0;
-        double stats[2] = {0.0, 1.0e12};
-        last_status = csp_minsnap_sample_batch(&d, tm.data(), co.data(), sample_distance, cap, samples.data(), &count, stats, nullptr);
-        if (last_status != CSP_OK || count > cap) {
-            std::cerr << "TrajectoryGeneratorTool::GenerateTrajectoryMatrix: sampling failed: " << csp_minsnap_strerror(last_status) << std::endl;
-            return MatrixXd();
-        }
         last_max_climb_rate = stats[0];
         last_min_turn_radius = stats[1];
         const long n = (long)count;

@@ -165,6 +165,28 @@ int csp_minsnap_sample_batch(const csp_minsnap_desc *desc, const void *times, co
                              double sample_distance, int64_t capacity, void *samples, int32_t *counts,
                              double *stats, void *hip_stream);
 
+/* Replaces the WHOLE of TrajectoryGeneratorTool::GenerateTrajectoryMatrix (minimum_snap.cpp:22-206) for a batch:
+ * csp_minsnap_plan_batch followed by csp_minsnap_sample_batch with the times and coefficients left on the device.
+ * Results are bit for bit those of the two calls.  A CSP_MEM_HOST caller -- the reference's own call pattern, one
+ * flight per call (uavPathPlanning.cpp:4423, :4461) -- pays ONE upload, ONE download and ONE synchronisation (a
+ * second round only when the re-solve loop had to raise somebody's weight).
+ *   capacity : rows of `samples` per trajectory (csp_minsnap_sample_capacity gives a sufficient value)
+ *   times, coeffs : optional outputs with CSP_MEM_HOST; REQUIRED (device buffers, they are the intermediates) with
+ *                   CSP_MEM_DEVICE
+ *   workspace : >= csp_minsnap_plan_workspace_bytes(desc) bytes (device); NULL/0 with CSP_MEM_HOST
+ * Everything else as in the two calls it stands for. */
+int csp_minsnap_generate_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
+                               const void *bc, double sample_distance, int64_t capacity, void *samples,
+                               int32_t *counts, double *stats, void *times, void *coeffs, double *max_dev,
+                               double *vel_zero_weight_out, int32_t *iterations, int32_t *status,
+                               void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* Upper bound of the samples any trajectory of the batch can produce (every candidate of the sampling loop,
+ * minimum_snap.cpp:126-161, plus the first and the last point), from HOST-resident waypoints: a `capacity` that
+ * csp_minsnap_generate_batch / csp_minsnap_sample_batch cannot overflow.  -1 for an invalid descriptor. */
+int64_t csp_minsnap_sample_capacity(const csp_minsnap_desc *desc, const void *waypoints_host, double v_avg,
+                                    double min_time_s);
+
 /* Name of the kernel csp_minsnap_solve_batch would dispatch for `desc` ("fixed_o4_s16_f64",
  * "generic_o4_f64", ...); NULL for an invalid descriptor.  For tests and profiles. */
 const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc);

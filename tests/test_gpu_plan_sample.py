@@ -238,3 +238,42 @@ def test_samplers_agree_with_fp32_storage(csp):
         torch.cuda.synchronize()
         assert got[0].dtype == torch.float32
         assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]), kw
+
+
+@pytest.mark.parametrize("order,pw,scale,v_avg,sd", [(2, 1e-7, 1500.0, 200.0, 300.0), (4, 0.0, 3.0, 5.0, 0.7), (3, 0.3, 4.0, 5.0, 0.5),
+                                                     (2, 0.3, 40000.0, 60.0, 250.0)])
+def test_generate_batch_is_plan_then_sample(csp, order, pw, scale, v_avg, sd):
+    """csp_minsnap_generate_batch (the whole GenerateTrajectoryMatrix in one call) against csp_minsnap_plan_batch
+    followed by csp_minsnap_sample_batch: bit for bit, from host memory (one upload / download / synchronisation; the
+    fourth case is ONE long flight whose sample block exceeds 1 MB, fetched in two steps; the third raises weights, so
+    the second round of the loop runs) and from device memory."""
+    import torch
+    for B in (1, 9):
+        wp, _ = synth.make_batch(B, 6, config_id=33 + order)
+        wp = wp * scale
+        bc = np.zeros((1, 4, 3))
+        bc[0, 0] = [0.3, -0.2, 0.1]
+        cap = csp.sample_capacity(wp, v_avg, 1.0, order=order)
+        p = csp.plan_batch(wp, v_avg, 1.0, bc=bc, order=order, path_weight=pw, vel_zero_weight=0.01)
+        s = csp.sample_batch(p.times, p.coeffs, sd, cap)
+        g = csp.generate_batch(wp, v_avg, 1.0, sd, bc=bc, order=order, path_weight=pw, vel_zero_weight=0.01)
+        assert g.samples.shape[1] == cap and int(s[1].max()) <= cap
+        if order == 3:
+            assert p.iterations.max() > 0          # the loop really ran
+        if scale == 40000.0 and B == 1:
+            assert cap * 24 > (1 << 20)
+        for name in ("times", "coeffs", "max_dev", "vel_zero_weight", "iterations", "status"):
+            assert np.array_equal(getattr(g, name), getattr(p, name)), (name, B)
+        assert np.array_equal(g.counts, s[1]) and np.array_equal(g.stats, s[2]), B
+        for b in range(B):
+            assert np.array_equal(g.samples[b, :g.counts[b]], s[0][b, :s[1][b]]), (B, b)
+        # device memory: asynchronous, same results
+        gd = csp.generate_batch(torch.from_numpy(wp).cuda(), v_avg, 1.0, sd, capacity=cap, bc=torch.from_numpy(bc).cuda(), order=order,
+                                path_weight=pw, vel_zero_weight=0.01)
+        pd = csp.plan_batch(torch.from_numpy(wp).cuda(), v_avg, 1.0, bc=torch.from_numpy(bc).cuda(), order=order, path_weight=pw,
+                            vel_zero_weight=0.01)
+        sd_ = csp.sample_batch(pd.times, pd.coeffs, sd, cap)
+        torch.cuda.synchronize()
+        assert torch.equal(gd.coeffs, pd.coeffs) and torch.equal(gd.counts, sd_[1]) and torch.equal(gd.samples, sd_[0])
+        assert torch.equal(gd.stats, sd_[2]) and torch.equal(gd.iterations, pd.iterations)
+        assert np.array_equal(gd.counts.cpu().numpy(), g.counts)
