@@ -5,6 +5,7 @@
 #include "../../include/csp_minsnap.h"
 #include "minsnap_launch.h"
 #include "minsnap_hoststage.h"
+#include "minsnap_timealloc.h"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -421,10 +422,10 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
     // the caller's output block and comes back with the results); phase 2 = the remaining <= 10 passes, checked per pass.
     int rc;
     hipError_t e;
-    if (phase != 2) {
-        csp::TimeAllocArgs ta;
-        ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
-        ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
+    csp::TimeAllocArgs ta;
+    ta.wp = waypoints; ta.times = times; ta.seg_off = s.ragged ? desc->seg_offsets : nullptr;
+    ta.B = s.B; ta.S = s.S; ta.v_avg = v_avg; ta.min_time_s = min_time_s;
+    if (phase != 2 && !(desc->path_weight > 0.0)) {   // with the loop: fused with the loop's initial state, below
         e = csp::launch_time_alloc(ta, s.f32, st);
         if (e != hipSuccess) return hip_fail(e, "time_alloc launch");
     }
@@ -461,7 +462,8 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
     // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
     int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
     if (phase != 2) {
-        if ((e = csp::launch_resolve_init(vw, iters, done, pending, desc->vel_zero_weight, s.B, st)) != hipSuccess) return hip_fail(e, "resolve_init");
+        if ((e = csp::launch_time_alloc_init(ta, s.f32, vw, iters, done, pending, desc->vel_zero_weight, st)) != hipSuccess)
+            return hip_fail(e, "time_alloc launch");
         if (desc->vel_zero_weight_per_traj)
             CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     }

@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, doubl
 }
 
 // Places the per-segment runs of sample_wave_seg_kernel: one wave per trajectory; prefix sum of the segment counts, coalesced
-// copies, the end-point rule (:157-160: present unless it duplicates the last recorded sample), the count.
+// copies, the end-point rule (:157-160: present unless it duplicates the last recorded sample), the count, the statistics.
 __global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts) {
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
@@ -749,9 +749,32 @@ __global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const do
             ++n;
         }
     }
-    if (lane == 0) {
-        a.counts[b] = (int32_t)n;
-        if (a.stats) { a.stats[b * 2] = 0.0; a.stats[b * 2 + 1] = 1.0e12; }   // overwritten by sample_stats_kernel (n <= capacity here)
+    if (lane == 0) a.counts[b] = (int32_t)n;
+    if (a.stats) {
+        // the statistics (:167-193) from the rows this wave has just placed (n <= capacity here): its own stores are
+        // complete after the fence; same loop as sample_stats_kernel, which a separate launch would cost ~5 us for
+        __threadfence();
+        SampleStats st;
+        st.max_climb = 0.0;
+        st.min_r = 1.0e12;
+        for (int64_t i = lane; i < n; i += 64) {
+            double p[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                p[q] = out[i * 3 + q];
+                st.p1[q] = i >= 1 ? out[(i - 1) * 3 + q] : 0.0;
+                st.p0[q] = i >= 2 ? out[(i - 2) * 3 + q] : 0.0;
+            }
+            st.n = i;
+            st.look(p);
+        }
+        double max_climb = st.max_climb, min_r = st.min_r;
+        for (int d = 1; d < 64; d <<= 1) {
+            const double oc = __shfl_xor(max_climb, d, 64), orr = __shfl_xor(min_r, d, 64);
+            max_climb = oc > max_climb ? oc : max_climb;
+            min_r = orr < min_r ? orr : min_r;
+        }
+        if (lane == 0) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
     }
 }
 
@@ -786,9 +809,6 @@ hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const i
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), block, 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);
-    if (a.stats)
-        hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, st, (const double *)a.samples, a.counts,
-                           a.stats, a.B, a.capacity);
     return hipGetLastError();
 }
 
