@@ -9,14 +9,17 @@
 // their inputs with ONE host-to-device copy and their outputs with ONE device-to-host copy through the
 // pinned block) and hands it back; nothing is freed until csp_minsnap_release_cached_memory().
 // Large transfers stream through the pinned block in two 8 MB halves: the DMA of one half overlaps the
-// CPU copy of the other.
+// CPU copy of the other (itself spread over a few helper threads, CopyPool); caller buffers that are
+// page-locked already are handed to the DMA engine directly.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstddef>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace csp {
@@ -109,6 +112,72 @@ inline void arena_free_idle() {
     if (have_cur) (void)hipSetDevice(cur);
 }
 
+// Staging copies of large batches are CPU-bound on one core (~10 GB/s against ~50 GB/s of PCIe): a few helper threads
+// (started at the first large transfer, idle on a condition variable otherwise, never joined -- the process may be
+// exiting when the library is unloaded) copy an 8 MB half in parallel slices.
+class CopyPool {
+public:
+    static CopyPool &get() { static CopyPool *p = new CopyPool(); return *p; }
+    // memcpy(dst, src, n) over the calling thread and the helpers; callers are serialised (one arena streams at a time)
+    void copy(void *dst, const void *src, size_t n) {
+        const size_t parts = workers_ + 1, piece = ((n / parts) + 4095) & ~(size_t)4095;
+        if (workers_ == 0 || n < ((size_t)1 << 20) || piece == 0) { std::memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> serial(call_);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = (char *)dst; src_ = (const char *)src; n_ = n; piece_ = piece;
+            pending_ = (int)workers_;
+            ++generation_;
+        }
+        cv_.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+    }
+
+private:
+    CopyPool() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        workers_ = hw >= 8 ? 3 : (hw >= 4 ? 1 : 0);
+        for (size_t w = 0; w < workers_; ++w) std::thread([this, w] { run(w + 1); }).detach();
+    }
+    void slice(size_t k) {
+        const size_t lo = k * piece_;
+        if (lo >= n_) return;
+        const size_t len = (k == workers_) ? n_ - lo : (lo + piece_ <= n_ ? piece_ : n_ - lo);
+        std::memcpy(dst_ + lo, src_ + lo, len);
+    }
+    void run(size_t k) {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            slice(k);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex m_, call_;
+    std::condition_variable cv_, done_;
+    size_t workers_ = 0, n_ = 0, piece_ = 0;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    int pending_ = 0;
+    unsigned long generation_ = 0;
+};
+
+// Page-locked (hipHostMalloc / hipHostRegister) caller memory needs no staging: the DMA engine reads and writes it directly.
+inline bool host_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 // One host-memory call: register the buffers, upload(), launch on ptr(offset), download().
 class HostCall {
 public:
@@ -139,15 +208,20 @@ public:
             return in_end_ ? hipMemcpyAsync(a_->dev, a_->pin, in_end_, hipMemcpyHostToDevice, st_) : hipSuccess;
         }
         size_t k = 0;   // running chunk counter over all items: the halves alternate across item boundaries too
-        for (const Item &it : ins_)
+        for (const Item &it : ins_) {
+            if (it.bytes >= ((size_t)1 << 20) && host_pinned(it.host)) {   // page-locked caller memory: one direct DMA
+                if ((e = hipMemcpyAsync(a_->dev + it.off, it.host, it.bytes, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
+                continue;
+            }
             for (size_t done = 0; done < it.bytes; done += Arena::HALF, ++k) {
                 const size_t n = it.bytes - done < Arena::HALF ? it.bytes - done : Arena::HALF;
                 char *half = a_->pin + (k & 1) * Arena::HALF;
                 if (k >= 2 && (e = hipEventSynchronize(a_->ev[k & 1])) != hipSuccess) return e;
-                std::memcpy(half, (const char *)it.host + done, n);
+                CopyPool::get().copy(half, (const char *)it.host + done, n);
                 if ((e = hipMemcpyAsync(a_->dev + it.off + done, half, n, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
                 if ((e = hipEventRecord(a_->ev[k & 1], st_)) != hipSuccess) return e;
             }
+        }
         return hipSuccess;
     }
 
@@ -170,8 +244,14 @@ public:
         if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;
         struct Chunk { const Item *it; size_t done, n; };
         std::vector<Chunk> ch;
+        bool direct = false;
         for (const Item &it : outs_) {
             if (!it.host) continue;
+            if (it.bytes >= ((size_t)1 << 20) && host_pinned(it.host)) {   // page-locked caller memory: one direct DMA
+                if ((e = hipMemcpyAsync(it.host, a_->dev + it.off, it.bytes, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
+                direct = true;
+                continue;
+            }
             for (size_t done = 0; done < it.bytes; done += Arena::HALF)
                 ch.push_back({&it, done, it.bytes - done < Arena::HALF ? it.bytes - done : Arena::HALF});
         }
@@ -184,8 +264,9 @@ public:
         for (size_t k = 0; k < ch.size(); ++k) {
             if (k + 1 < ch.size() && (e = issue(k + 1)) != hipSuccess) return e;   // DMA of the next half overlaps this copy
             if ((e = hipEventSynchronize(a_->ev[k & 1])) != hipSuccess) return e;
-            std::memcpy((char *)ch[k].it->host + ch[k].done, a_->pin + (k & 1) * Arena::HALF, ch[k].n);
+            CopyPool::get().copy((char *)ch[k].it->host + ch[k].done, a_->pin + (k & 1) * Arena::HALF, ch[k].n);
         }
+        if (direct && (e = hipStreamSynchronize(st_)) != hipSuccess) return e;
         dirty_ = false;
         return hipSuccess;
     }

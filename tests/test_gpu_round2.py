@@ -445,3 +445,22 @@ def test_status_flags_with_the_two_coefficient_test(csp, order, S):
             assert flagged == bad, (order, S, pw, r.kernel, flagged)
             good = np.setdiff1d(np.arange(B), bad)
             assert np.isfinite(r.coeffs[good]).all()
+
+
+def test_large_host_batches_pageable_and_pinned(csp):
+    """Host-memory batches beyond the 16 MB staging block: pageable caller memory streams through the pinned halves with
+    the staging copies spread over helper threads; page-locked caller memory (here: torch pinned tensors viewed as
+    numpy) is read and written by the DMA engine directly.  Both bit-equal with the device-memory call."""
+    import torch
+    B, S = 40000, 16
+    wp, tm = synth.make_batch(B, S, config_id=77)
+    ref = csp.solve_batch(torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda(), order=4).coeffs.cpu().numpy()
+    got = csp.solve_batch(wp, tm, order=4).coeffs                       # pageable in, pageable out (123 MB)
+    assert np.array_equal(got, ref)
+    pwp, ptm = torch.from_numpy(wp).pin_memory(), torch.from_numpy(tm).pin_memory()
+    pout = torch.empty((B, S, 3, 8), dtype=torch.float64).pin_memory()
+    pout.fill_(-1.0)
+    r = csp.solve_batch(pwp.numpy(), ptm.numpy(), order=4, out=pout.numpy())
+    assert np.array_equal(r.coeffs, ref) and np.array_equal(pout.numpy(), ref)
+    # mixed: pinned inputs, pageable output
+    assert np.array_equal(csp.solve_batch(pwp.numpy(), ptm.numpy(), order=4).coeffs, ref)
