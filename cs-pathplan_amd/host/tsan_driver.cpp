@@ -3,7 +3,8 @@
 // -fsanitize=thread, linked with the ordinary kernel objects, plus this driver.  Without a device every compute entry
 // returns CSP_ERR_NO_DEVICE after its validation and device probing, which is the code that runs here: argument
 // validation, kernel selection / naming (thread-local buffers), the thread-local HIP error text, the sharded entry's
-// device enumeration, and the staging-arena pool (mutex-protected free lists shared by all threads of a process).
+// device enumeration, the staging-arena pool (mutex-protected free lists shared by all threads of a process) and the
+// helper threads of the staging copies (CopyPool).
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +53,14 @@ static void worker(int id) {
         csp::arena_release(b);
         csp::arena_release(a);
         if (it % 97 == 0) csp_minsnap_release_cached_memory();
+        // the staging-copy pool: several callers at once (the sharded entry's per-device threads do that), odd sizes
+        if (it % 50 == 0) {
+            const size_t n = ((size_t)3 << 20) + 4097 * (size_t)(id + 1) + (size_t)it;
+            std::vector<unsigned char> src(n), dst(n, 0);
+            for (size_t i = 0; i < n; i += 509) src[i] = (unsigned char)(i * 31 + id);
+            csp::CopyPool::get().copy(dst.data(), src.data(), n);
+            if (std::memcmp(dst.data(), src.data(), n) != 0) ++failures;
+        }
     }
 }
 
