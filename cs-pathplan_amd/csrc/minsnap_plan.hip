@@ -389,6 +389,11 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
 // third of this kernel's time for a flight of six 60-second legs.  With dt = 0.1 (every segment of >= 1 s) the sequence
 // is the same for every segment of every call: `tacc[k]` = the (k+1)-th accumulated time, built once per device by one
 // lane doing the additions in order (tacc_init_kernel), turns the 63 additions into one coalesced load.
+// A window switches to the "dense" chain (every lane finds its own successor among the next 16 candidates through LDS,
+// ~2 k clocks whatever the window holds) when the previous window recorded at least this many samples; the sparse chain
+// costs one ballot round (~130 clocks) per RECORDED sample.  Measured on one flight of six 12-km legs (3600 candidates):
+// threshold 4 / 8 / 16 / never: 74.6 / 64.6 / 64.8 / 64.6 us at 166 samples, 112 / 109 / 112 / 139 us at 1149 samples.
+constexpr int CSP_DENSE_MIN = 16;
 constexpr int TACC_N = 8192;   // candidates per segment covered by the table (819 s of flight per segment)
 __global__ void tacc_init_kernel(double *tab, int n) {
     double t = 0.1;
@@ -461,7 +466,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a, const dou
         return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     };
     const double sd2 = a.keep_dist2;
-    bool dense = false;      // the previous window recorded >= 4 samples (wave-uniform)
+    bool dense = false;      // the previous window recorded >= CSP_DENSE_MIN samples (wave-uniform)
     for (int seg = 0; seg < S; ++seg) {
         const IO *rec = (a.seg_major && !a.seg_off) ? (const IO *)a.coeffs + ((int64_t)seg * a.B + b) * 3 * M
                                                      : (const IO *)a.coeffs + (seg0 + seg) * 3 * M;
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a, const dou
                 n += cnt;
                 nb += cnt;
                 if (nb >= 64) flush();
-                dense = cnt >= 4;
+                dense = cnt >= CSP_DENSE_MIN;
             } else {
                 dense = false;
             }
@@ -699,7 +704,7 @@ __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, doubl
 #pragma unroll
             for (int q = 0; q < 3; ++q) prev[q] = bcast(cur[q], lastl);
             n += cnt;
-            dense = cnt >= 4;
+            dense = cnt >= CSP_DENSE_MIN;
         } else {
             dense = false;
         }
