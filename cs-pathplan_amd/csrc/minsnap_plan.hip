@@ -718,24 +718,39 @@ __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, doubl
     if (lane == 0) seg_counts[g] = (int32_t)n;
 }
 
-// Places the per-segment runs of sample_wave_seg_kernel: one wave per trajectory; prefix sum of the segment counts, coalesced
+// Places the per-segment runs of sample_wave_seg_kernel: one workgroup per trajectory; prefix sum of the segment counts, coalesced
 // copies, the end-point rule (:157-160: present unless it duplicates the last recorded sample), the count, the statistics.
-__global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts) {
-    const int lane = threadIdx.x;
+// FOUR waves per trajectory and four elements in flight per lane: with one wave and one element the copy is a chain of
+// dependent load -> store round trips (47 us for 2129 samples).
+__global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts) {
+    __shared__ double l_red[2 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b = blockIdx.x;
     int64_t seg0;
     int S;
     if (a.seg_off) { seg0 = a.seg_off[b]; S = (int)(a.seg_off[b + 1] - seg0); }
     else { seg0 = b * (int64_t)a.S; S = a.S; }
     double *out = (double *)a.samples + b * a.capacity * 3;
+    const int64_t room = a.capacity * 3;
     int64_t n = 0;
     for (int seg = 0; seg < S; ++seg) {
         const int64_t g = seg0 + seg;
-        const int cnt = seg_counts[g];
+        const int64_t cnt3 = (int64_t)seg_counts[g] * 3;
         const double *src = tmp + tmp_off[g] * 3;
-        for (int64_t e = lane; e < (int64_t)cnt * 3; e += 64)
-            if (n * 3 + e < a.capacity * 3) out[n * 3 + e] = src[e];
-        n += cnt;
+        for (int64_t e0 = tid; e0 < cnt3; e0 += 4 * 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e = e0 + u * 256;
+                v[u] = src[e < cnt3 ? e : cnt3 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e = e0 + u * 256;
+                if (e < cnt3 && n * 3 + e < room) out[n * 3 + e] = v[u];
+            }
+        }
+        n += seg_counts[g];
     }
     if (S > 0) {
         const int64_t gl = seg0 + S - 1;
@@ -750,19 +765,21 @@ __global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const do
             add = sqrt(dx * dx + dy * dy + dz * dz) > 1e-6;
         }
         if (add) {
-            if (lane < 3 && n < a.capacity) out[n * 3 + lane] = pe[lane];
+            if (tid < 3 && n < a.capacity) out[n * 3 + tid] = pe[tid];
             ++n;
         }
     }
-    if (lane == 0) a.counts[b] = (int32_t)n;
+    if (tid == 0) a.counts[b] = (int32_t)n;
     if (a.stats) {
-        // the statistics (:167-193) from the rows this wave has just placed (n <= capacity here): its own stores are
-        // complete after the fence; same loop as sample_stats_kernel, which a separate launch would cost ~5 us for
+        // the statistics (:167-193) from the rows this workgroup has just placed (n <= capacity here): its stores are
+        // complete and visible after fence + barrier; same per-sample code as sample_stats_kernel, which a separate
+        // launch would cost ~5 us for
         __threadfence();
+        __syncthreads();
         SampleStats st;
         st.max_climb = 0.0;
         st.min_r = 1.0e12;
-        for (int64_t i = lane; i < n; i += 64) {
+        for (int64_t i = tid; i < n; i += 256) {
             double p[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -779,7 +796,16 @@ __global__ void __launch_bounds__(64) sample_place_kernel(SampleArgs a, const do
             max_climb = oc > max_climb ? oc : max_climb;
             min_r = orr < min_r ? orr : min_r;
         }
-        if (lane == 0) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+        if (lane == 0) { l_red[wave] = max_climb; l_red[4 + wave] = min_r; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) {
+                max_climb = l_red[w] > max_climb ? l_red[w] : max_climb;
+                min_r = l_red[4 + w] < min_r ? l_red[4 + w] : min_r;
+            }
+            a.stats[b * 2] = max_climb;
+            a.stats[b * 2 + 1] = min_r;
+        }
     }
 }
 
@@ -813,7 +839,7 @@ hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const i
         case 5: hipLaunchKernelGGL((sample_wave_seg_kernel<5>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
         default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), block, 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);
+    hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), dim3(256), 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);
     return hipGetLastError();
 }
 
