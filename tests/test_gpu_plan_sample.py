@@ -277,3 +277,54 @@ def test_generate_batch_is_plan_then_sample(csp, order, pw, scale, v_avg, sd):
         assert torch.equal(gd.coeffs, pd.coeffs) and torch.equal(gd.counts, sd_[1]) and torch.equal(gd.samples, sd_[0])
         assert torch.equal(gd.stats, sd_[2]) and torch.equal(gd.iterations, pd.iterations)
         assert np.array_equal(gd.counts.cpu().numpy(), g.counts)
+
+
+def test_generate_batch_ragged_host_call(csp):
+    """csp_minsnap_generate_batch through the raw C-ABI with a RAGGED host batch (seg_offsets): every trajectory equals
+    the uniform single-trajectory call, bit for bit -- with the path penalty on (the loop's state is per trajectory) and
+    long legs (the per-segment wave sampler with runs sized from the host's estimate of the times)."""
+    import ctypes
+    lens = [3, 6, 2, 5]
+    order, v_avg, sd = 3, 40.0, 25.0
+    rng = np.random.default_rng(12)
+    wps = [np.cumsum(rng.normal(scale=900.0, size=(n + 1, 3)), axis=0) for n in lens]
+    wp = np.ascontiguousarray(np.concatenate(wps))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B, total = len(lens), int(off[-1])
+    bc = np.zeros((1, 4, 3))
+    d = csp.make_desc(order, B, 0, csp.DTYPE_F64, 0.3, 0.01, csp.MEM_HOST, seg_offsets_ptr=off.ctypes.data, max_segments=max(lens))
+    cap = int(csp.raw_lib().csp_minsnap_sample_capacity(ctypes.byref(d), wp.ctypes.data, v_avg, 1.0))
+    assert cap > 0
+    smp = np.zeros((B, cap, 3))
+    cnt = np.zeros(B, dtype=np.int32)
+    st = np.zeros((B, 2))
+    tm = np.zeros(total)
+    co = np.zeros((total, 3, 2 * order))
+    md, vw = np.zeros(B), np.zeros(B)
+    it, sta = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+    rc = csp.raw_lib().csp_minsnap_generate_batch(ctypes.byref(d), wp.ctypes.data, v_avg, 1.0, bc.ctypes.data, sd, cap, smp.ctypes.data,
+                                                 cnt.ctypes.data, st.ctypes.data, tm.ctypes.data, co.ctypes.data, md.ctypes.data,
+                                                 vw.ctypes.data, it.ctypes.data, sta.ctypes.data, None, 0, None)
+    assert rc == 0, rc
+    assert tm.max() / 0.1 > 300      # long legs
+    for b, n in enumerate(lens):
+        # the ragged batch runs the generic kernel, the uniform single call the register-resident one: same results up to
+        # rounding (the sampling decisions are far from ties here)
+        one = csp.generate_batch(wps[b][None], v_avg, 1.0, sd, capacity=cap, order=order, path_weight=0.3, vel_zero_weight=0.01)
+        assert np.array_equal(one.times[0], tm[off[b]:off[b + 1]]), b
+        assert synth.rel_err(co[off[b]:off[b + 1]].reshape(1, -1), one.coeffs[0].reshape(1, -1)) < 1e-9, b
+        assert one.counts[0] == cnt[b] and one.iterations[0] == it[b] and one.vel_zero_weight[0] == vw[b], b
+        scale = np.max(np.abs(one.samples[0, :cnt[b]]))
+        assert np.max(np.abs(one.samples[0, :cnt[b]] - smp[b, :cnt[b]])) < 1e-8 * scale, b
+        assert np.allclose(one.stats[0], st[b], rtol=1e-6), b
+    # and the ragged call against the two ragged calls it stands for: bit for bit
+    tm2, co2 = np.zeros(total), np.zeros((total, 3, 2 * order))
+    md2, vw2, it2, sta2 = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+    rc = csp.raw_lib().csp_minsnap_plan_batch(ctypes.byref(d), wp.ctypes.data, v_avg, 1.0, bc.ctypes.data, tm2.ctypes.data, co2.ctypes.data,
+                                             md2.ctypes.data, vw2.ctypes.data, it2.ctypes.data, sta2.ctypes.data, None, 0, None)
+    assert rc == 0
+    assert np.array_equal(tm2, tm) and np.array_equal(co2, co) and np.array_equal(it2, it) and np.array_equal(vw2, vw)
+    s2 = csp.sample_batch(tm2, co2, sd, cap, order=order, seg_offsets=off)
+    assert np.array_equal(s2[1], cnt) and np.array_equal(s2[2], st)
+    for b in range(B):
+        assert np.array_equal(s2[0][b, :cnt[b]], smp[b, :cnt[b]]), b
