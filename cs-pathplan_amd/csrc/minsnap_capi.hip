@@ -415,7 +415,7 @@ namespace {
 int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoints, double v_avg, double min_time_s,
                 const void *bc, void *times, void *coeffs, double *max_dev, double *vel_zero_weight_out,
                 int32_t *iterations, int32_t *status, void *workspace, size_t workspace_bytes, hipStream_t st,
-                bool sync_early_exit, int phase = 0, int32_t *pending_ext = nullptr) {
+                bool sync_early_exit, int phase = 0, int32_t *pending_ext = nullptr, int32_t **done_out = nullptr) {
     // phase 0: everything (device-memory callers; host callers that check after every pass).  The host wrapper splits the
     // call so that the common case -- every trajectory converged at its FIRST solve -- costs one synchronisation:
     // phase 1 = time allocation + first solve + bookkeeping, nothing synchronised (the "increases so far" counter sits in
@@ -478,7 +478,9 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
         rc = dispatch(&g, gs, waypoints, times, bc, coeffs, md, status, desc->seg_offsets, vw, workspace, solve_ws, st, done,
                       tau_buf, pass == 0 ? 1 : 2);
         if (rc != CSP_OK) return rc;
-        if ((e = csp::launch_resolve_update(md, vw, iters, done, count ? pending : nullptr, s.B, st)) != hipSuccess)
+        // `done_out` (phase 1 only): the caller's next kernel does this pass's update (sample placement, one launch less)
+        if (phase == 1 && done_out) *done_out = done;
+        else if ((e = csp::launch_resolve_update(md, vw, iters, done, count ? pending : nullptr, s.B, st)) != hipSuccess)
             return hip_fail(e, "resolve_update");
         if (sync_early_exit && phase != 1) {
             int32_t increased = 0;   // cumulative: a pass that raised nobody's weight was the last one anybody needed
@@ -800,14 +802,18 @@ int csp_minsnap_generate_batch(const csp_minsnap_desc *desc, const void *waypoin
         // round 0: time allocation + first solve (+ bookkeeping); round 1 (only if somebody's weight was raised): the
         // remaining <= 10 passes, checked one by one.  Sampling and ONE copy back follow either.
         if (round) hc.touch();
+        int32_t *done_dev = nullptr;   // first pass of the loop + per-segment sampler: the placement kernel does the pass's update
+        const bool fold = loop && round == 0 && !run_off.empty();
         rc = plan_device(&dd, s, hc.ptr(o_wp), v_avg, min_time_s, hc.ptr(o_bc), hc.ptr(o_tm), hc.ptr(o_co), hc.ptr<double>(o_md),
                          hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), hc.ptr<int32_t>(o_st), hc.ptr(o_ws), n_ws, st, true,
-                         loop ? round + 1 : 0, loop ? hc.ptr<int32_t>(o_pd) : nullptr);
+                         loop ? round + 1 : 0, loop ? hc.ptr<int32_t>(o_pd) : nullptr, fold ? &done_dev : nullptr);
         if (rc != CSP_OK) return rc;
         hipError_t e;
-        if (!run_off.empty())
-            e = csp::launch_sample_segment_waves(a, hc.ptr<double>(o_tmp), hc.ptr<const int64_t>(o_ro), hc.ptr<int32_t>(o_sc), total_seg, st);
-        else
+        if (!run_off.empty()) {
+            const csp::LoopUpdate upd = {hc.ptr<double>(o_md), hc.ptr<double>(o_vw), hc.ptr<int32_t>(o_it), done_dev, hc.ptr<int32_t>(o_pd)};
+            e = csp::launch_sample_segment_waves_upd(a, hc.ptr<double>(o_tmp), hc.ptr<const int64_t>(o_ro), hc.ptr<int32_t>(o_sc), total_seg,
+                                                     fold && done_dev ? &upd : nullptr, st);
+        } else
             e = csp::launch_sample(a, s.f32, st);
         if (e != hipSuccess) return hip_fail(e, "sample launch");
         CSP_HIP(hc.download());

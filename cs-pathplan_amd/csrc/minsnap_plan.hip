@@ -8,7 +8,7 @@
 // for trajectories of up to 64 segments and one lane per trajectory beyond.
 #include <mutex>
 
-#include "minsnap_launch.h"
+#include "minsnap_timealloc.h"
 
 namespace csp {
 
@@ -722,7 +722,8 @@ __global__ void __launch_bounds__(64) sample_wave_seg_kernel(SampleArgs a, doubl
 // copies, the end-point rule (:157-160: present unless it duplicates the last recorded sample), the count, the statistics.
 // FOUR waves per trajectory and four elements in flight per lane: with one wave and one element the copy is a chain of
 // dependent load -> store round trips (47 us for 2129 samples).
-__global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts) {
+__global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const double *tmp, const int64_t *tmp_off, const int32_t *seg_counts,
+                                                           LoopUpdate upd) {
     __shared__ double l_red[2 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b = blockIdx.x;
@@ -770,6 +771,16 @@ __global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const d
         }
     }
     if (tid == 0) a.counts[b] = (int32_t)n;
+    if (tid == 0 && upd.done && !upd.done[b]) {   // resolve_update_kernel's step for this trajectory (first pass of the loop)
+        if (upd.max_dev[b] > 0.2 && upd.iters[b] < 10) {
+            const double w = upd.vw[b];
+            upd.vw[b] = (w < 1e-6) ? 0.01 : w * 2.0;
+            upd.iters[b] += 1;
+            if (upd.pending) atomicAdd(upd.pending, 1);
+        } else {
+            upd.done[b] = 1;
+        }
+    }
     if (a.stats) {
         // the statistics (:167-193) from the rows this workgroup has just placed (n <= capacity here): its stores are
         // complete and visible after fence + barrier; same per-sample code as sample_stats_kernel, which a separate
@@ -828,6 +839,11 @@ static const double *tacc_table(hipStream_t st) {
 
 hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
                                        int64_t total_segments, hipStream_t st) {
+    return launch_sample_segment_waves_upd(a, tmp, tmp_off, seg_counts, total_segments, nullptr, st);
+}
+
+hipError_t launch_sample_segment_waves_upd(const SampleArgs &a, double *tmp, const int64_t *tmp_off, int32_t *seg_counts,
+                                           int64_t total_segments, const LoopUpdate *upd, hipStream_t st) {
     if (a.B == 0 || total_segments == 0) return hipSuccess;
     const dim3 grid((unsigned)total_segments), block(64);
     const double *tacc = tacc_table(st);
@@ -839,7 +855,9 @@ hipError_t launch_sample_segment_waves(const SampleArgs &a, double *tmp, const i
         case 5: hipLaunchKernelGGL((sample_wave_seg_kernel<5>), grid, block, 0, st, a, tmp, tmp_off, seg_counts, tacc); break;
         default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), dim3(256), 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts);
+    const LoopUpdate none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(sample_place_kernel, dim3((unsigned)a.B), dim3(256), 0, st, a, (const double *)tmp, tmp_off, (const int32_t *)seg_counts,
+                       upd ? *upd : none);
     return hipGetLastError();
 }
 

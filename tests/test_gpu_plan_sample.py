@@ -307,6 +307,7 @@ def test_generate_batch_ragged_host_call(csp):
                                                  vw.ctypes.data, it.ctypes.data, sta.ctypes.data, None, 0, None)
     assert rc == 0, rc
     assert tm.max() / 0.1 > 300      # long legs
+    assert it.max() > 0, it    # weights were raised: the second round of the call ran, after the folded first-pass update
     for b, n in enumerate(lens):
         # the ragged batch runs the generic kernel, the uniform single call the register-resident one: same results up to
         # rounding (the sampling decisions are far from ties here)
