@@ -51,6 +51,19 @@ namespace fixedk {
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for every
 // outstanding global store (vmcnt(0)); the persistent kernel keeps stores and the next
 // slice's LDS-DMA in flight across its barriers.
+// 16-byte coefficient store.  `nt` (wave-uniform, GenericArgs::nt_stores): non-temporal, for batches whose coefficients
+// exceed the Infinity Cache -- B = 524288: 348 us against 378 us (67.9 % against 62.5 % of HBM peak); at B = 65536, whose
+// 201 MB the cache absorbs, the ordinary store is the faster one (42.5 us against 46.1 us), so the launcher decides.
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(char *p, const double2 &v, bool nt) {
+    if (nt) {
+        v2d_t x = {v.x, v.y};
+        __builtin_nontemporal_store(x, reinterpret_cast<v2d_t *>(p));
+    } else {
+        *reinterpret_cast<double2 *>(p) = v;
+    }
+}
+
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -479,13 +492,14 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
         if (paired) {
             // pair base = record of the even segment; TOP meets the odd record first, BOTTOM the even one
             char *pbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + (g & ~1)) * L::REC);  // uniform
+            const bool nt = a.nt_stores != 0;
             if (first) {
                 double2 v[8];   // 8 rows x 128 bytes per store
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l8 + i * 8 * ROW);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 0 : 256) + (size_t)i * 8 * RS + o8) = v[i];
+                    store16(pbase + (BOTTOM ? 0 : 256) + (size_t)i * 8 * RS + o8, v[i], nt);
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {  // 4 rows x 256 bytes per store, two batches of 8
@@ -494,7 +508,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                     for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l16 + (h * 8 + i) * 4 * ROW);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        *reinterpret_cast<double2 *>(pbase + (BOTTOM ? 128 : 0) + (size_t)(h * 8 + i) * 4 * RS + o16) = v[i];
+                        store16(pbase + (BOTTOM ? 128 : 0) + (size_t)(h * 8 + i) * 4 * RS + o16, v[i], nt);
                 }
             }
         } else {
@@ -508,12 +522,12 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 #pragma unroll
                     for (int i = 0; i < NFULL; ++i)
                         v[i] = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
+                    const bool nt = a.nt_stores != 0;
 #pragma unroll
-                    for (int i = 0; i < NFULL; ++i)
-                        *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v[i];
+                    for (int i = 0; i < NFULL; ++i) store16(gbase + (size_t)i * L::RPI * RS + g_off, v[i], nt);
                     if (NFULL < L::NI && NFULL * L::RPI + grp < 64)   // the ragged last store
-                        *reinterpret_cast<double2 *>(gbase + (size_t)NFULL * L::RPI * RS + g_off) =
-                            *reinterpret_cast<const double2 *>(stage + lds_off + NFULL * L::RPI * ROW);
+                        store16(gbase + (size_t)NFULL * L::RPI * RS + g_off,
+                                *reinterpret_cast<const double2 *>(stage + lds_off + NFULL * L::RPI * ROW), nt);
                 }
             } else {
                 // the axis-per-lane mapping serves slices of <= 16 rows: only the first stores can hold one
@@ -759,6 +773,14 @@ inline bool axis_lanes_enabled() {   // CSP_AXIS_LANES=0 switches the three-lane
     return on;
 }
 
+// Non-temporal coefficient stores (store16) once the coefficients of the launch exceed the 256 MB Infinity Cache;
+// CSP_NT_STORES=0 / 1 forces the choice (A/B runs).
+inline int nt_stores_for(int64_t B, int S, int O) {
+    static const int forced = [] { const char *e = std::getenv("CSP_NT_STORES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (forced >= 0) return forced;
+    return (double)B * S * 6 * O * 8.0 > 256.0 * 1024 * 1024 ? 1 : 0;
+}
+
 template <int O, int S, bool SEGMAJ_OK>
 hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
     const dim3 block(128);
@@ -799,6 +821,7 @@ hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
         if (n_full) {
             GenericArgs f = a;
             f.B = n_full * 64;
+            f.nt_stores = nt_stores_for(a.B, S, O);
             if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, S, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
             else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
         }

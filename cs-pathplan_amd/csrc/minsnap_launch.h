@@ -34,6 +34,8 @@ struct GenericArgs {
     int tau_mode;           // path kernel: 0 find t* each call; 1 find and store in tstar; 2 reuse tstar (re-solve loop)
     int slice_w = 64;       // fixed kernels, one-workgroup-per-slice variant: trajectories per workgroup (small batches
                             // are cut into narrower slices so that every CU gets one, see fixedk::narrow_slice)
+    int nt_stores = 0;      // fixed kernels, whole slices: non-temporal coefficient stores -- set by the launcher for
+                            // batches whose coefficients exceed the Infinity Cache (fixedk::store16)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);
