@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-template <bool ROWS>
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// NT: the stores carry the non-temporal bit (what the solver does for launches beyond the Infinity Cache)
+template <bool ROWS, bool NT>
 __global__ void __launch_bounds__(128) io_kernel(const double2 *in, double2 *out, int n_slices) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int s = blockIdx.x; s < n_slices; s += gridDim.x) {
@@ -29,7 +32,8 @@ __global__ void __launch_bounds__(128) io_kernel(const double2 *in, double2 *out
                 off = (size_t)(wave * 96 + k) * 1024 + (size_t)lane * 16;
             }
             acc.x += 1.0;
-            *reinterpret_cast<double2 *>(dst + off) = acc;
+            if (NT) { v2d_t x = {acc.x, acc.y}; __builtin_nontemporal_store(x, reinterpret_cast<v2d_t *>(dst + off)); }
+            else *reinterpret_cast<double2 *>(dst + off) = acc;
         }
     }
 }
@@ -45,26 +49,27 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int per_cu = 2; per_cu <= 16; per_cu *= 2)
+    for (int nt = 0; nt < 2; ++nt)
+    for (int per_cu = 2; per_cu <= 8; per_cu *= 2)
     for (int mode = 0; mode < 2; ++mode) {
         const int grid = per_cu * p.multiProcessorCount;
-        for (int w = 0; w < 3; ++w) {
-            if (mode) hipLaunchKernelGGL(io_kernel<true>, dim3(grid), dim3(128), 0, 0, in, out, n_slices);
-            else hipLaunchKernelGGL(io_kernel<false>, dim3(grid), dim3(128), 0, 0, in, out, n_slices);
-        }
+        auto launch = [&] {
+            if (mode) { if (nt) hipLaunchKernelGGL((io_kernel<true, true>), dim3(grid), dim3(128), 0, 0, in, out, n_slices);
+                        else hipLaunchKernelGGL((io_kernel<true, false>), dim3(grid), dim3(128), 0, 0, in, out, n_slices); }
+            else { if (nt) hipLaunchKernelGGL((io_kernel<false, true>), dim3(grid), dim3(128), 0, 0, in, out, n_slices);
+                   else hipLaunchKernelGGL((io_kernel<false, false>), dim3(grid), dim3(128), 0, 0, in, out, n_slices); }
+        };
+        for (int w = 0; w < 3; ++w) launch();
         hipEventRecord(e0, 0);
         const int reps = 20;
-        for (int r = 0; r < reps; ++r) {
-            if (mode) hipLaunchKernelGGL(io_kernel<true>, dim3(grid), dim3(128), 0, 0, in, out, n_slices);
-            else hipLaunchKernelGGL(io_kernel<false>, dim3(grid), dim3(128), 0, 0, in, out, n_slices);
-        }
+        for (int r = 0; r < reps; ++r) launch();
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
         const double bytes = (double)n_slices * (34816.0 + 196608.0);
-        std::printf("{\"workgroups_per_cu\": %d, \"store_shape\": \"%s\", \"B\": %d, \"us\": %.1f, \"TBps\": %.3f, \"frac_of_8TBps\": %.3f}\n", per_cu, mode ? "rows (4 x 256 B per wave instruction)" : "linear (1 KB per wave instruction)",
+        std::printf("{\"nt_stores\": %d, \"workgroups_per_cu\": %d, \"store_shape\": \"%s\", \"B\": %d, \"us\": %.1f, \"TBps\": %.3f, \"frac_of_8TBps\": %.3f}\n", nt, per_cu, mode ? "rows (4 x 256 B per wave instruction)" : "linear (1 KB per wave instruction)",
                     B, ms * 1e3, bytes / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 8e12);
     }
     return 0;
