@@ -1,5 +1,8 @@
-import importlib, sys, numpy as np
-sys.path.insert(0, "/root/repo")
+"""Diagnostic (not collected by pytest; run on a GPU box as `python tests/probe_f32_storage.py`): error of fp32 STORAGE
+(CSP_DTYPE_F32, fp64 arithmetic) and of fp64 against the 80-bit oracle on a ragged mix, per order.  Lives under tests/
+because it uses the oracle as the checker."""
+import importlib, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 csp = importlib.import_module("cs-pathplan_amd")
 import oracle
 from tests import synth
