@@ -775,8 +775,12 @@ inline bool axis_lanes_enabled() {   // CSP_AXIS_LANES=0 switches the three-lane
 
 // Non-temporal coefficient stores (store16) once the coefficients of the launch exceed the 256 MB Infinity Cache;
 // CSP_NT_STORES=0 / 1 forces the choice (A/B runs).
-inline int nt_stores_for(int64_t B, int S, int O) {
+inline int nt_forced() {
     static const int forced = [] { const char *e = std::getenv("CSP_NT_STORES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced;
+}
+inline int nt_stores_for(int64_t B, int S, int O) {
+    const int forced = nt_forced();
     if (forced >= 0) return forced;
     return (double)B * S * 6 * O * 8.0 > 256.0 * 1024 * 1024 ? 1 : 0;
 }

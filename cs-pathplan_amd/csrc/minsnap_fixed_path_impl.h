@@ -410,7 +410,7 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 const int row = i * L::RPI + grp;
                 if (lane < L::RPI * L::LPR && row < rows && !l_skip[row]) {
                     const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
-                    *reinterpret_cast<double2 *>(gbase + (size_t)i * L::RPI * RS + g_off) = v2;
+                    store16(gbase + (size_t)i * L::RPI * RS + g_off, v2, a.nt_stores != 0);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -566,8 +566,15 @@ minsnap_fixed_path_kernel(GenericArgs a) {
 
 template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream_t st) {
     const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
-    if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, a);
+    GenericArgs f = a;
+    // Coefficients beyond the Infinity Cache: non-temporal stores (store16) -- order 4 only.  Measured at S = 16
+    // (tools/path_nt_ab.py, two boxes): order 4, B = 131072 / 262144 / 524288: 188 / 368 / 723 us against 214 / 419 /
+    // 817 us with ordinary stores (32.6 % against 28.9 % of HBM peak at B = 524288).  Orders 2 and 3 LOSE (B = 524288:
+    // 503 against 306 us, 876 against 620 us): their 96- and 144-byte records leave 128-byte lines shared between
+    // store instructions, and a non-temporal partial line is not merged on the way out.
+    f.nt_stores = O == 4 || nt_forced() == 1 ? nt_stores_for(a.B, S, O) : 0;
+    if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
+    else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();
 }
 
