@@ -87,6 +87,36 @@ def test_c4_full_size_on_one_gpu(csp, oracle_mod):
         assert torch.equal(part, c[lo:lo + 65536])
 
 
+def test_path_kernel_beyond_the_infinity_cache(csp, oracle_mod):
+    """Order 4 with both penalties at B = 131072 x 16 segments (403 MB of coefficients): the launch takes non-temporal
+    coefficient stores (launch_path_s); its two halves solved on their own (201 MB each: ordinary stores) must give the
+    same bits -- coefficients, max_dev and status -- and a subsample spread over the batch agrees with the oracle.
+    Order 2 (the shipped yaml; ordinary stores at every size) the same way."""
+    import torch
+    for o, tol in ((4, NORTH_STAR_TOL), (2, NORTH_STAR_TOL)):
+        B, S, H = 131072, 16, 65536
+        wp, tm = synth.make_batch(B, S, config_id=40 + o)
+        d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+        kw = dict(order=o, path_weight=1e-7, vel_zero_weight=0.01, want_status=True, want_max_dev=True)
+        r = csp.solve_batch(d_wp, d_tm, **kw)
+        torch.cuda.synchronize()
+        assert r.kernel == "fixedpath_o%d_s16_f64" % o, r.kernel
+        assert int(r.status.abs().max()) == 0
+        for lo in (0, H):
+            part = csp.solve_batch(d_wp[lo:lo + H].contiguous(), d_tm[lo:lo + H].contiguous(), **kw)
+            assert torch.equal(part.coeffs, r.coeffs[lo:lo + H]), (o, lo)
+            assert torch.equal(part.max_dev, r.max_dev[lo:lo + H]), (o, lo)
+            del part
+        idx = np.linspace(0, B - 1, 96).astype(np.int64)
+        ref, dev = oracle_mod.solve_batch(o, wp[idx], tm[idx], path_weight=1e-7, vel_zero_weight=0.01, nthreads=oracle_mod.max_threads())
+        got = r.coeffs[torch.from_numpy(idx).cuda()].cpu().numpy()
+        e = synth.rel_err_per_power(got, ref)
+        print("path kernel order %d, B = %d: per-power rel err vs the oracle %.2e" % (o, B, e))
+        assert e < tol, (o, e)
+        del r, d_wp, d_tm
+        torch.cuda.empty_cache()
+
+
 def test_f5b_s64_fixtures(csp, oracle_mod):
     for c in load_cases("F5b_ragged_s64.json"):
         o, S = c["order"], c["segments"]
