@@ -567,12 +567,15 @@ minsnap_fixed_path_kernel(GenericArgs a) {
 template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream_t st) {
     const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
     GenericArgs f = a;
-    // Coefficients beyond the Infinity Cache: non-temporal stores (store16) -- order 4 only.  Measured at S = 16
-    // (tools/path_nt_ab.py, two boxes): order 4, B = 131072 / 262144 / 524288: 188 / 368 / 723 us against 214 / 419 /
-    // 817 us with ordinary stores (32.6 % against 28.9 % of HBM peak at B = 524288).  Orders 2 and 3 LOSE (B = 524288:
-    // 503 against 306 us, 876 against 620 us): their 96- and 144-byte records leave 128-byte lines shared between
-    // store instructions, and a non-temporal partial line is not merged on the way out.
-    f.nt_stores = O == 4 || nt_forced() == 1 ? nt_stores_for(a.B, S, O) : 0;
+    // Non-temporal coefficient stores (store16) at order 4, at every batch size (CSP_NT_STORES=0 / 1 forces the choice
+    // for A/B runs).  Measured at S = 16 (tools/path_nt_ab.py; three boxes): B = 16384 / 32768 / 65536 / 98304 / 131072 /
+    // 262144 / 524288: 40.7 / 45.1 / 93-95 / 145 / 188 / 368 / 723 us against 44.1 / 49.3 / 95.5-97.6 / 163 / 214 / 419 /
+    // 817 us with ordinary stores, and WRITE_SIZE 1.013x the coefficients instead of 1.083x: unlike the unpenalised
+    // kernel (section 5.1: ordinary stores win while the coefficients fit the Infinity Cache) this one computes for most
+    // of its time and gains from lines that leave whole.  Orders 2 and 3 LOSE at every size (B = 524288: 503 against
+    // 306 us, 876 against 620 us): their 96- and 144-byte records leave 128-byte lines shared between store
+    // instructions, and a non-temporal partial line is not merged on the way out.
+    f.nt_stores = O == 4 ? (nt_forced() == 0 ? 0 : 1) : (nt_forced() == 1 ? 1 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();
