@@ -825,7 +825,11 @@ hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
         if (n_full) {
             GenericArgs f = a;
             f.B = n_full * 64;
-            f.nt_stores = nt_stores_for(a.B, S, O);
+            // order 4 only: its paired 192-byte records leave whole 128-byte lines per store instruction.  The 96- / 144- /
+            // 240-byte records of orders 2 / 3 / 5 share lines between instructions, which the L2 merges for ordinary
+            // stores and not for non-temporal ones -- B = 524288, S = 16 (S = 8 at order 5): 261 / 392 / 312 us with
+            // ordinary stores against 499 / 841 / 404 us with non-temporal ones (tools/fixed_nt_ab.py)
+            f.nt_stores = O == 4 ? nt_stores_for(a.B, S, O) : (nt_forced() == 1 ? 1 : 0);
             if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, S, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
             else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
         }
