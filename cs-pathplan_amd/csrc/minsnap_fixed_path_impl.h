@@ -567,15 +567,19 @@ minsnap_fixed_path_kernel(GenericArgs a) {
 template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream_t st) {
     const dim3 grid((unsigned)((a.B + 63) / 64)), block(128);
     GenericArgs f = a;
-    // Non-temporal coefficient stores (store16) at order 4, at every batch size (CSP_NT_STORES=0 / 1 forces the choice
-    // for A/B runs).  Measured at S = 16 (tools/path_nt_ab.py; three boxes): B = 16384 / 32768 / 65536 / 98304 / 131072 /
+    // Non-temporal coefficient stores (store16) at order 4 from 48 MB of coefficients on (CSP_NT_STORES=0 / 1 forces the
+    // choice for A/B runs).  Measured at S = 16 (tools/path_nt_ab.py; three boxes): B = 16384 / 32768 / 65536 / 98304 / 131072 /
     // 262144 / 524288: 40.7 / 45.1 / 93-95 / 145 / 188 / 368 / 723 us against 44.1 / 49.3 / 95.5-97.6 / 163 / 214 / 419 /
     // 817 us with ordinary stores, and WRITE_SIZE 1.013x the coefficients instead of 1.083x: unlike the unpenalised
     // kernel (section 5.1: ordinary stores win while the coefficients fit the Infinity Cache) this one computes for most
     // of its time and gains from lines that leave whole.  Orders 2 and 3 LOSE at every size (B = 524288: 503 against
     // 306 us, 876 against 620 us): their 96- and 144-byte records leave 128-byte lines shared between store
     // instructions, and a non-temporal partial line is not merged on the way out.
-    f.nt_stores = O == 4 ? (nt_forced() == 0 ? 0 : 1) : (nt_forced() == 1 ? 1 : 0);
+    // Launches that write less than 48 MB keep ordinary stores: nothing measurable to gain (B = 8192: 40.2 against
+    // 40.6 us; one order-4 flight through the host C-ABI: 1167-1186 us either way), and the reader that follows a small
+    // solve (the sampler) then finds the coefficients in the cache.
+    const bool big = (double)a.B * S * 6 * O * 8.0 >= 48.0 * 1024 * 1024;
+    f.nt_stores = nt_forced() >= 0 ? nt_forced() : (O == 4 && big ? 1 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();
