@@ -183,6 +183,63 @@ __device__ __forceinline__ void recover(double Ps, double dP, const double (&xs)
     c[M - 1] = Ps;
 }
 
+
+// ---- whole-line coefficient stores (round 3) -----------------------------------------------------------------------
+// A role's records of one trajectory are one contiguous byte range [LO, HI) of the coeffs array, produced record by
+// record (top role: descending segments, bottom role: ascending).  Records of 96 / 144 / 240 bytes (orders 2 / 3 / 5) do not
+// end on 128-byte lines, so a record-at-a-time store leaves lines shared between two store instructions issued a whole
+// segment apart: the L2 has to merge the halves (WRITE_SIZE 1.08-1.14x the coefficients) and non-temporal stores, which
+// are not merged, lose 1.3-2x.  Here each staging-tile row is a RING of trajectory bytes (position = byte offset mod RINGB):
+// a record is written into the ring, every 128-byte line it COMPLETES is stored whole (8 rows x 128 bytes per store
+// instruction, 8 lanes per line), and the bytes of a line still waiting for the next record stay in the ring (< 128 of
+// them, so RINGB = record + held bytes rounded up to a line).  Lines cut by the role boundary (HT * RECB not on a line) leave as
+// the part this role owns.  Needs trajectories that start on a line: (S * RECB) % 128 == 0.  All of it is compile-time
+// arithmetic once the segment loop is unrolled.
+template <int O, int S> struct LineGeom {
+    static constexpr int RECB = 48 * O;                       // bytes per (trajectory, segment) record
+    static constexpr bool OK = (S * RECB) % 128 == 0;
+    // bytes waiting for their line are a multiple of gcd(RECB, 128) below 128: 96 / 112 / 64 / 112 at orders 2 / 3 / 4 / 5
+    static constexpr int GCD = RECB % 128 == 0 ? 128 : (RECB % 64 == 0 ? 64 : (RECB % 32 == 0 ? 32 : 16));
+    static constexpr int RINGB = ((RECB + 128 - GCD + 127) / 128) * 128;
+    static constexpr int ROW = RINGB / 8 + 2;                 // doubles; stride in dwords = odd multiple of 4
+    static constexpr int MAXL = RECB / 128 + 1;               // lines one record can complete
+};
+template <int O, int S, bool BOTTOM> struct LineRing {
+    using G = LineGeom<O, S>;
+    static constexpr int RECB = G::RECB, HT = (S + 1) / 2;
+    static constexpr int LO = BOTTOM ? HT * RECB : 0, HI = BOTTOM ? S * RECB : HT * RECB;
+    static constexpr int RS = S * RECB;                        // bytes between consecutive trajectories
+    static constexpr int LINES = BOTTOM ? (HI / 128 - LO / 128) : (HI + 127) / 128;   // lines (whole or cut) of this role
+    // ring position, in doubles, of trajectory byte x
+    __device__ static __forceinline__ constexpr int pos(int x) { return (x % G::RINGB) / 8; }
+    // Stores the lines completed by record g (already in the ring).  tbase: the slice's first trajectory in coeffs
+    // (wave-uniform).  PRED: rows may be dead (ragged slice, skip mask): bit i of live8 = row i*8 + lane/8 is stored.
+    template <bool PRED>
+    __device__ static __forceinline__ void flush(int g, const double *stage, char *tbase, int lane, bool nt, unsigned live8) {
+        const int q = lane >> 3, p = lane & 7;
+        const int l_lane = q * G::ROW + p * 2;
+        const unsigned g_lane = (unsigned)(q * RS + p * 16);
+        const int rlo = g * RECB, rhi = rlo + RECB;
+        // top role (written = [rlo, HI)): lines that START inside the record; bottom role (written = [LO, rhi)): lines that END inside it
+        const int l0 = BOTTOM ? rlo / 128 : (rlo + 127) / 128;
+        const int nl = BOTTOM ? rhi / 128 - rlo / 128 : (rhi + 127) / 128 - (rlo + 127) / 128;
+#pragma unroll
+        for (int k = 0; k < G::MAXL; ++k) {
+            if (k < nl) {
+                const int ell = l0 + k;
+                const bool whole = BOTTOM ? ell * 128 >= LO : ell * 128 + 128 <= HI;
+                const bool pv = whole || (BOTTOM ? ell * 128 + p * 16 >= LO : ell * 128 + p * 16 < HI);
+                double2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(stage + l_lane + pos(ell * 128) + i * 8 * G::ROW);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (pv && (!PRED || ((live8 >> i) & 1u))) store16(tbase + ell * 128 + (size_t)i * 8 * RS + g_lane, v[i], nt);
+            }
+        }
+    }
+};
+
 // LDS geometry of one workgroup (64 trajectories, two waves)
 template <int O, int S> struct FixedLds {
     static constexpr int HT = (S + 1) / 2, HB = S / 2;  // segments of the top / bottom role
@@ -192,7 +249,8 @@ template <int O, int S> struct FixedLds {
                                                      // copy-in write linearly; the few time reads tolerate conflicts)
     // staging row: the record (+ for order 4 the 8 doubles held over from the pair's other record),
     // padded so that the row stride in dwords is an odd multiple of 4 (conflict-free ds_write_b128)
-    static constexpr int STAGE_ROW = O == 4 ? 34 : (O == 2 ? 14 : REC);
+    // (whole-line rings, LineGeom, where the trajectories start on lines)
+    static constexpr int STAGE_ROW = LineGeom<O, S>::OK ? LineGeom<O, S>::ROW : (O == 4 ? 34 : (O == 2 ? 14 : REC));
     static constexpr int WP_DOUBLES = 64 * WP_ROW;
     static constexpr int TM_DOUBLES = 64 * TM_ROW;
     static constexpr int STAGE_DOUBLES = 64 * STAGE_ROW;  // per wave
@@ -407,6 +465,9 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
     // 256-byte run.  Every line is then written whole (the single-record scheme left 1/3 of the lines
     // half-written between two bursts and measured +8 % WRITE_SIZE).  Lane maps of the burst shapes:
     constexpr bool PAIRING = FULL && !SEGMAJ && O == 4 && (S % 2) == 0;
+    // the other orders: whole-line ring (LineRing above) wherever the trajectories start on 128-byte lines
+    constexpr bool RING = FULL && !SEGMAJ && !PAIRING && NAX == 3 && LineGeom<O, S>::OK;
+    using LR = LineRing<O, S, BOTTOM>;
     const int grp = lane / L::LPR;                 // LPR lanes per record (lanes >= RPI*LPR idle)
     const int lane_in = lane - grp * L::LPR;
     const int lds_off = grp * ROW + lane_in * 2;   // doubles
@@ -474,7 +535,8 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                 double2 v2;
                 v2.x = c[i];
                 v2.y = c[i + 1];
-                *reinterpret_cast<double2 *>(stage + row * ROW + tpos + i) = v2;
+                const int at = RING ? LR::pos(g * RECB + ((ax0 + ax) * M + i) * 8) : tpos + i;
+                *reinterpret_cast<double2 *>(stage + row * ROW + at) = v2;
             }
             if (STATUS) {
                 // Non-finite values are caught on the highest-power and the constant coefficient: every endpoint
@@ -511,6 +573,8 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
                         store16(pbase + (BOTTOM ? 128 : 0) + (size_t)(h * 8 + i) * 4 * RS + o16, v[i], nt);
                 }
             }
+        } else if (RING) {
+            LR::template flush<false>(g, stage, reinterpret_cast<char *>((double *)a.coeffs + b0 * S * L::REC), lane, a.nt_stores != 0, 0xffu);
         } else {
             char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (SEGMAJ ? ((int64_t)g * a.Btotal + a.Boffset + b0) : (b0 * S + g)) * L::REC);  // uniform
             if (FULL) {
@@ -700,7 +764,8 @@ __device__ __forceinline__ void persistent_role_loop(const GenericArgs &a, int n
     // this many younger operations existing).  Paired records (order 4, default layout): 8 + 16
     // stores per pair; single records: NI each.
     constexpr int PAIRS = (SEGMAJ || O != 4 || (S % 2) != 0) ? 0 : HS / 2;
-    constexpr int STORES_PER_SLICE = PAIRS * 24 + (HS - 2 * PAIRS) * L::NI;
+    constexpr bool RING = !SEGMAJ && O != 4 && LineGeom<O, S>::OK;   // as in fixed_body: 8 stores per line of the role
+    constexpr int STORES_PER_SLICE = RING ? LineRing<O, S, BOTTOM>::LINES * 8 : PAIRS * 24 + (HS - 2 * PAIRS) * L::NI;
     // Batch-wide boundary conditions / weight are read once, before the loop: a global load inside
     // the loop could only be waited for together with every older store.  (Per-trajectory boundary
     // conditions or weights take the one-workgroup-per-slice kernel instead, see launch_hs.)
@@ -825,11 +890,12 @@ hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
         if (n_full) {
             GenericArgs f = a;
             f.B = n_full * 64;
-            // order 4 only: its paired 192-byte records leave whole 128-byte lines per store instruction.  The 96- / 144- /
-            // 240-byte records of orders 2 / 3 / 5 share lines between instructions, which the L2 merges for ordinary
-            // stores and not for non-temporal ones -- B = 524288, S = 16 (S = 8 at order 5): 261 / 392 / 312 us with
-            // ordinary stores against 499 / 841 / 404 us with non-temporal ones (tools/fixed_nt_ab.py)
-            f.nt_stores = O == 4 ? nt_stores_for(a.B, S, O) : (nt_forced() == 1 ? 1 : 0);
+            // Non-temporal stores need lines that leave whole: order 4 (paired 192-byte records) and, from round 3 on, every
+            // order whose trajectories start on 128-byte lines (LineRing).  Record-at-a-time stores of 96- / 144- / 240-byte
+            // records share lines between instructions, which the L2 merges for ordinary stores and not for non-temporal
+            // ones (round 2, B = 524288: 261 / 392 / 312 us ordinary against 499 / 841 / 404 us non-temporal).
+            constexpr bool WHOLE_LINES = !SM && (O == 4 || LineGeom<O, S>::OK);
+            f.nt_stores = (WHOLE_LINES || O == 4) ? nt_stores_for(a.B, S, O) : (nt_forced() == 1 ? 1 : 0);
             if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, S, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
             else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
         }

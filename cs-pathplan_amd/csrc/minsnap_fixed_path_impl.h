@@ -241,6 +241,18 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
     const int grp = lane / L::LPR, lane_in = lane - grp * L::LPR;
     const int lds_off = grp * ROW + lane_in * 2;
     const unsigned g_off = (unsigned)(grp * RS + lane_in * 16);
+    // whole-line stores through the ring of minsnap_fixed_impl.h (LineRing) wherever the trajectories start on 128-byte
+    // lines; the dense order-2 variant keeps its 96-byte tile rows (no room for a ring under 40 KB of LDS)
+    constexpr bool RING = PEN && LineGeom<O, S>::OK && !path_dense<O, S>;
+    using LR = LineRing<O, S, BOTTOM>;
+    unsigned live8 = 0;   // bit i: row i*8 + lane/8 is a live trajectory of this slice
+    if (RING) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + (lane >> 3);
+            live8 |= (r < rows && !l_skip[r]) ? (1u << i) : 0u;
+        }
+    }
 #pragma unroll
     for (int j = HS - 1; j >= 0; --j) {
         double xk[N][3];
@@ -355,7 +367,8 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                     double2 v2;
                     v2.x = c[i];
                     v2.y = c[i + 1];
-                    *reinterpret_cast<double2 *>(stage + lane * ROW + ax * M + i) = v2;
+                    const int at = RING ? LR::pos(g * RECB + (ax * M + i) * 8) : ax * M + i;
+                    *reinterpret_cast<double2 *>(stage + lane * ROW + at) = v2;
                 }
                 if (STATUS) {
                     // Non-finite values are caught on the highest-power and the constant coefficient: every endpoint
@@ -404,13 +417,17 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 maxdev = ratio > maxdev ? ratio : maxdev;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * L::REC);
+            if (RING) {
+                LR::template flush<true>(g, stage, reinterpret_cast<char *>((double *)a.coeffs + b0 * S * L::REC), lane, a.nt_stores != 0, live8);
+            } else {
+                char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * L::REC);
 #pragma unroll
-            for (int i = 0; i < L::NI; ++i) {
-                const int row = i * L::RPI + grp;
-                if (lane < L::RPI * L::LPR && row < rows && !l_skip[row]) {
-                    const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
-                    store16(gbase + (size_t)i * L::RPI * RS + g_off, v2, a.nt_stores != 0);
+                for (int i = 0; i < L::NI; ++i) {
+                    const int row = i * L::RPI + grp;
+                    if (lane < L::RPI * L::LPR && row < rows && !l_skip[row]) {
+                        const double2 v2 = *reinterpret_cast<const double2 *>(stage + lds_off + i * L::RPI * ROW);
+                        store16(gbase + (size_t)i * L::RPI * RS + g_off, v2, a.nt_stores != 0);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -579,7 +596,10 @@ template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream
     // 40.6 us; one order-4 flight through the host C-ABI: 1167-1186 us either way), and the reader that follows a small
     // solve (the sampler) then finds the coefficients in the cache.
     const bool big = (double)a.B * S * 6 * O * 8.0 >= 48.0 * 1024 * 1024;
-    f.nt_stores = nt_forced() >= 0 ? nt_forced() : (O == 4 && big ? 1 : 0);
+    // Round 3: orders 2 / 3 store whole lines too (LineRing) where the trajectories start on lines -- except the dense
+    // order-2 variant -- and take the same rule.
+    constexpr bool WHOLE_LINES = O == 4 || (LineGeom<O, S>::OK && !path_dense<O, S>);
+    f.nt_stores = nt_forced() >= 0 ? nt_forced() : (WHOLE_LINES && big ? 1 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();
