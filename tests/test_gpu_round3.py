@@ -85,3 +85,55 @@ def test_whole_line_stores_beyond_the_infinity_cache(csp, order, S, B):
     torch.cuda.synchronize()
     assert torch.equal(whole[:h], lo) and torch.equal(whole[h:], hi)
     assert bool(torch.isfinite(whole).all())
+
+
+@pytest.mark.parametrize("order,S", [(2, 4), (3, 8), (3, 16), (4, 8), (4, 16)])
+def test_path_kernel_whole_line_stores_and_the_skip_mask(csp, oracle_mod, order, S):
+    """The path-penalty kernels store through the same ring (LineRing::flush<PRED = true>): dead rows -- the ragged last
+    slice, and trajectories the re-solve loop has finished (skip mask) -- must stay untouched while their neighbours'
+    lines leave whole.  (a) one solve against the generic kernel on a ragged multi-slice batch; (b) the re-solve loop on a
+    batch where slice 0 converges at once and slice 1 converges every other trajectory (as
+    test_resolve_loop_with_converged_slices does for order 4, S = 6), against the oracle's loop."""
+    import torch
+    rng = np.random.default_rng(40 + order * 17 + S)
+    B = 64 * 11 + 29
+    wp, tm = synth.make_batch(B, S, config_id=85 + order)
+    bc = rng.normal(size=(B, 4, 3))
+    d = [torch.from_numpy(x).cuda() for x in (wp, tm, bc)]
+    kw = dict(order=order, path_weight=0.7, vel_zero_weight=0.03, want_status=True, want_max_dev=True)
+    r = csp.solve_batch(d[0], d[1], d[2], **kw)
+    g = csp.solve_batch(d[0], d[1], d[2], force_generic=True, **kw)
+    torch.cuda.synchronize()
+    assert r.kernel == "fixedpath_o%d_s%d_f64" % (order, S)
+    assert synth.rel_err(r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()) < 1e-8
+    assert float((r.max_dev - g.max_dev).abs().max()) < 1e-8 * max(1.0, float(g.max_dev.max()))
+    # (b) the loop
+    B = 64 * 3 + 17
+    wig, _ = synth.make_batch(B, S, config_id=26)
+    wig = wig * 4.0
+    t = np.linspace(0.0, 1.0, S + 1)[None, :, None]
+    span = rng.uniform(20, 60, size=(B, 1, 3))
+    straight = rng.uniform(-50, 50, size=(B, 1, 3)) + t * span + rng.normal(scale=0.02, size=(B, S + 1, 3))
+    vdir = 5.0 * span[:, 0, :] / np.linalg.norm(span[:, 0, :], axis=1, keepdims=True)
+    wp, bc = wig.copy(), np.zeros((B, 4, 3))
+    sel = np.zeros(B, dtype=bool)
+    sel[:64] = True
+    sel[64:128:2] = True
+    wp[sel] = straight[sel]
+    bc[sel, 0] = vdir[sel]
+    bc[sel, 1] = vdir[sel]
+    plan = csp.plan_batch(torch.from_numpy(wp).cuda(), 5.0, 0.1, bc=torch.from_numpy(bc).cuda(), order=order,
+                          path_weight=0.3, vel_zero_weight=0.0)
+    torch.cuda.synchronize()
+    it = plan.iterations.cpu().numpy()
+    co, md, vwo = plan.coeffs.cpu().numpy(), plan.max_dev.cpu().numpy(), plan.vel_zero_weight.cpu().numpy()
+    n_loop = 0
+    for b in (0, 5, 63, 64, 65, 66, 67, 127, 128, 150, B - 1):
+        ref, info = oracle_mod.generate_trajectory(wp[b], order=order, path_weight=0.3, vel_zero_weight=0.0, v_avg=5.0,
+                                                   min_time_s=0.1, sample_distance=1.0, bc=bc[b])
+        assert it[b] == info["iters"], (b, it[b], info["iters"])
+        n_loop += int(it[b] > 0)
+        assert abs(vwo[b] - info["vel_zero_weight"]) <= 1e-15
+        assert abs(md[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
+        assert synth.rel_err_per_power(co[b], info["coeff"]) < 1e-6, b
+    assert n_loop > 0 and (it[:64] == 0).all()
