@@ -236,6 +236,7 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
             for (int ax = 0; ax < 3; ++ax) xn[r][ax] = R[r][ax];
     }
 
+    if (PEN) CSP_STAMP(3);
     // ---- backward sweep ----
     constexpr int RECB = L::REC * 8, RS = S * RECB, ROW = path_stage_row<O, S>;
     const int grp = lane / L::LPR, lane_in = lane - grp * L::LPR;
@@ -316,6 +317,25 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
             // (most of the register file) and the kernel spills.
             double best_lo = 0.0, best_hi = -1.0;
             int g_lo = 0, g_hi = 16;                  // global sample indices
+            if constexpr (O == 2) {
+                // Order 2: q is LINEAR in u per axis, so |q(u)|^2 = A + u Bc + u^2 C with three scalars per segment
+                // (A = |q0|^2, Bc = 2 q0.q1, C = |q1|^2): 5 operations per sample pair instead of ~20, and the pairs
+                // unrolled (u, u^2 and the weights are literals).  The search was 13 k of a wave's 57 k clocks -- and
+                // what a workgroup does before its first store is what the whole launch waits for (round 3 stamps).
+                const double A = __builtin_fma(cq[2][0], cq[2][0], __builtin_fma(cq[1][0], cq[1][0], cq[0][0] * cq[0][0]));
+                const double C = __builtin_fma(cq[2][1], cq[2][1], __builtin_fma(cq[1][1], cq[1][1], cq[0][1] * cq[0][1]));
+                const double Bc = 2.0 * __builtin_fma(cq[2][0], cq[2][1], __builtin_fma(cq[1][0], cq[1][1], cq[0][0] * cq[0][1]));
+#pragma unroll
+                for (int p_ = 7; p_ >= 1; --p_) {
+                    const double u = (double)p_ * 0.0625, u2 = u * u;
+                    const double hw = 0.25 - u2, wgt = hw * hw;
+                    const double t = __builtin_fma(u2, C, A);
+                    const double sp = __builtin_fma(u, Bc, t), sm = __builtin_fma(-u, Bc, t);
+                    const double lo = wgt * (BOTTOM ? sp : sm), hi = wgt * (BOTTOM ? sm : sp);
+                    if (lo > best_lo) { best_lo = lo; g_lo = 8 - p_; }
+                    if (hi >= best_hi) { best_hi = hi; g_hi = 8 + p_; }
+                }
+            } else {
 #pragma unroll 1
             for (int p_ = 7; p_ >= 1; --p_) {
                 const double u = (double)p_ * 0.0625, u2 = u * u;
@@ -338,6 +358,7 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 const double lo = wgt * (BOTTOM ? sp : sm), hi = wgt * (BOTTOM ? sm : sp);
                 if (lo > best_lo) { best_lo = lo; g_lo = 8 - p_; }
                 if (hi >= best_hi) { best_hi = hi; g_hi = 8 + p_; }
+            }
             }
             double best = best_lo;
             int best_g = g_lo;
@@ -475,11 +496,14 @@ __device__ __forceinline__ void path_role(const GenericArgs &a, int64_t b0, int 
         }
     }
     spd = true;  // the reported status is the penalised solve's
+    CSP_STAMP(2);
     path_sweep<O, S, BOTTOM, true, STATUS>(a, b0, rows, lane, in, rbc, a.path_weight, l_hw, stage, xchg, partner_xchg, l_skip, tau, spd, nanacc, maxdev);
     // the reference's max_deviation is the maximum over ALL segments and the status covers both
     // halves: the bottom role hands its part to the top role, which writes (plain stores, and only
     // for live trajectories: a re-solve pass must leave finished trajectories untouched)
     const int bits = (spd ? 0 : 2) | ((nanacc == 0.0) ? 0 : 1);
+    CSP_STAMP(4);
+    CSP_STAMP_RT(6);
     lds_barrier();
     if (BOTTOM) { l_dev[lane] = maxdev; l_bits[lane] = bits; }
     lds_barrier();
@@ -522,6 +546,8 @@ minsnap_fixed_path_kernel(GenericArgs a) {
         const int sk = lane < rows ? a.skip[b0 + lane] : 1;
         if (__builtin_amdgcn_ballot_w64(sk == 0) == 0) return;
     }
+    CSP_STAMP_RT(5);
+    CSP_STAMP(0);
     if constexpr (DENSE) {
         // A workgroup stores nothing before its backward sweep: started together, the resident workgroups compute with
         // the memory system idle and then all store at once (time = compute-before-the-first-store + bytes / bandwidth:
@@ -575,6 +601,7 @@ minsnap_fixed_path_kernel(GenericArgs a) {
         if (tid < 64) l_skip[tid] = (tid < rows && a.skip) ? a.skip[b0 + tid] : 0;
     }
     __syncthreads();
+    CSP_STAMP(1);
     int64_t b = b0 + lane;
     if (b >= a.B) b = a.B - 1;
     if (role == 0) path_role<O, S, false, STATUS, DENSE>(a, b0, rows, b, lane, l_wp, l_tm, l_hw, l_stage, l_stage, l_stage + TILE, l_skip, l_dev, l_bits);

@@ -2,6 +2,12 @@
 // (minsnap_fixed_path_impl.h) for derivative order 2, S = 2..16 segments.
 #include "minsnap_fixed_path_impl.h"
 
+#ifdef CSP_STAMPS
+extern "C" int csp_debug_read_stamps_path_o2(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(csp_g_stamps), n * sizeof(unsigned long long));
+}
+#endif
+
 namespace csp {
 
 hipError_t launch_fixedpath_o2(const GenericArgs &a, hipStream_t st) {

@@ -13,7 +13,19 @@ from tests.conftest import load_cases
 
 pytestmark = pytest.mark.gpu
 
-TOL_WELL = 1e-8      # well-scaled synthetic inputs, fp64
+# Every gate below is the PER-POWER relative error (tests/synth.py::parity_gate); tolerances placed from a survey run on
+# the MI355X (CSP_PARITY_SURVEY, numbers in DESIGN.md section 3)
+# the MI355X (CSP_PARITY_SURVEY=file; round 3, 7828 gate evaluations; the measured maximum is quoted beside each):
+TOL_WELL = 5e-8         # HIP vs the fp64 dense oracle, well-scaled inputs, orders <= 4: measured <= 6.2e-9 (the oracle's own rounding)
+TOL_O5 = 1e-6           # order-5 fixtures (cond ~1e9 in the dense formulation): 6.7e-8
+TOL_PEN = 5e-8          # with the path penalty: 3.7e-9
+TOL_KERNELS = 1e-8      # two HIP kernels against each other, orders <= 4: 3.1e-9 (chunked/span), 2e-10 (fixed)
+TOL_KERNELS_O5 = 1e-7   # order 5, S <= 8: 5.5e-9
+TOL_KERNELS_PATH = 1e-9 # path kernel vs generic: 5.8e-11
+# Order 5 beyond a few segments: the fp64 dense oracle itself is 3e-6 ... 9e-6 per power from the 80-bit answer at S = 64
+# (DESIGN.md section 3), so order-5 results are gated against the 80-bit oracle at the north-star tolerance; two HIP kernel
+# families agree to 8.2e-6 per power at S = 69 (cond(R_PP) ~ 1e8 -- the spline problem's own conditioning): gate 5e-5.
+TOL_KERNELS_O5_LONG = 5e-5
 NORTH_STAR_TOL = 1e-6
 
 
@@ -33,11 +45,10 @@ def test_golden_unpenalised(csp, fname):
     for c in load_cases(fname):
         for force in (True, False):
             r = _solve_case(csp, c, force_generic=force)
-            err = synth.rel_err(r.coeffs.reshape(1, -1), c["coeff"].reshape(1, -1))
             # order 5 systems are the worst conditioned of the fixture set (cond ~1e9 in the
             # dense formulation): both sides carry ~1e-9 of their own rounding
-            tol = 1e-7 if c["order"] == 5 else TOL_WELL
-            assert err < tol, (c["name"], r.kernel, err)
+            tol = TOL_O5 if c["order"] == 5 else TOL_WELL
+            synth.parity_gate(r.coeffs[0], c["coeff"], tol, (fname, c["name"], r.kernel))
             assert int(r.status[0]) == 0, (c["name"], r.status)
             assert abs(r.max_dev[0] - c["max_dev"]) < 1e-9
 
@@ -45,8 +56,7 @@ def test_golden_unpenalised(csp, fname):
 def test_golden_penalties(csp):
     for c in load_cases("F6_penalties.json"):
         r = _solve_case(csp, c)
-        err = synth.rel_err(r.coeffs.reshape(1, -1), c["coeff"].reshape(1, -1))
-        assert err < 1e-7, (c["name"], r.kernel, err)
+        synth.parity_gate(r.coeffs[0], c["coeff"], TOL_PEN, ("F6", c["name"], r.kernel))
         assert abs(r.max_dev[0] - c["max_dev"]) < 1e-7 * max(1.0, abs(c["max_dev"])), (c["name"], r.max_dev[0], c["max_dev"])
 
 
@@ -82,8 +92,7 @@ def test_seeded_batch_vs_oracle(csp, oracle_mod, S, B):
     ref, _ = oracle_mod.solve_batch(4, wp, tm, nthreads=oracle_mod.max_threads())
     for force in (True, False):
         r = csp.solve_batch(wp, tm, order=4, want_status=True, force_generic=force)
-        err = synth.rel_err(r.coeffs, ref)
-        assert err < TOL_WELL, (r.kernel, err)
+        synth.parity_gate(r.coeffs, ref, TOL_WELL, ("seeded", S, r.kernel))
         assert not r.status.any()
 
 
@@ -100,10 +109,10 @@ def test_fixed_kernel_every_bucket_and_ragged_tails(csp, oracle_mod, S):
         assert r.kernel == "fixed_o4_s%d_f64" % S
         assert not r.status.any() and not r.max_dev.any()
         g = csp.solve_batch(wp, tm, bc, order=4, vel_zero_weight_per_traj=vw, force_generic=True)
-        assert synth.rel_err(r.coeffs, g.coeffs) < 1e-9, (S, B)
+        synth.parity_gate(r.coeffs, g.coeffs, TOL_KERNELS, ("every_bucket vs generic", S, B))
         for b in (0, B - 1):
             ref, _ = oracle_mod.solve(4, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], 0.0, float(vw[b]))
-            assert synth.rel_err(r.coeffs[b].reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, (S, B, b)
+            synth.parity_gate(r.coeffs[b], ref, TOL_WELL, ("every_bucket vs oracle", S, B, b))
 
 
 @pytest.mark.parametrize("S", [2, 3, 4, 6, 7, 8, 13, 16])
@@ -122,10 +131,10 @@ def test_persistent_workgroups_walk_several_slices(csp, oracle_mod, S):
         a, g = a.cpu().numpy(), g.cpu().numpy()
         if seg_major:
             a, g = np.transpose(a, (1, 0, 2, 3)), np.transpose(g, (1, 0, 2, 3))
-        assert synth.rel_err(a, g) < 1e-9, (S, seg_major)
+        synth.parity_gate(a, g, TOL_KERNELS, ("persistent vs generic", S, seg_major))
     idx = np.array([0, 63, 64, 32768, 40000, B - 6, B - 1])
     ref, _ = oracle_mod.solve_batch(4, wp[idx], tm[idx])
-    assert synth.rel_err(a[idx], ref) < TOL_WELL
+    synth.parity_gate(a[idx], ref, TOL_WELL, ("persistent vs oracle", S))
 
 
 @pytest.mark.parametrize("order,S_list", [(2, [2, 5, 16]), (3, [3, 4, 11, 16]), (5, [2, 5, 8])])
@@ -146,11 +155,11 @@ def test_fixed_kernels_of_the_other_orders(csp, oracle_mod, order, S_list):
             torch.cuda.synchronize()
             assert not r.status.cpu().numpy().any()
             a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
-            assert synth.rel_err(a, gg) < (1e-7 if order == 5 else 1e-9), (order, S, B)
+            synth.parity_gate(a, gg, TOL_KERNELS_O5 if order == 5 else TOL_KERNELS, ("other orders vs generic", order, S, B))
             for b in sorted({0, B // 2, B - 1}):
-                ref, _ = oracle_mod.solve(order, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], 0.0, float(vw[b]))
-                tol = 1e-6 if order == 5 else TOL_WELL
-                assert synth.rel_err(a[b].reshape(1, -1), ref.reshape(1, -1)) < tol, (order, S, B, b)
+                # order 5: against the 80-bit oracle (the fp64 dense restatement is 1.2e-6 per power off at S = 8 already)
+                ref, _ = oracle_mod.solve(order, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], 0.0, float(vw[b]), long_double=order == 5)
+                synth.parity_gate(a[b], ref, NORTH_STAR_TOL if order == 5 else TOL_WELL, ("other orders vs oracle", order, S, B, b))
 
 
 @pytest.mark.parametrize("order,S_list", [(2, [2, 3, 6, 16]), (3, [2, 5, 12, 16]), (4, [2, 3, 7, 8, 13, 16])])
@@ -173,12 +182,12 @@ def test_path_penalty_register_kernel(csp, oracle_mod, order, S_list):
             torch.cuda.synchronize()
             assert not r.status.cpu().numpy().any()
             a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
-            assert synth.rel_err(a, gg) < 1e-8, (order, S, B)
+            synth.parity_gate(a, gg, TOL_KERNELS_PATH, ("path kernel vs generic", order, S, B))
             md, mdg = r.max_dev.cpu().numpy(), g.max_dev.cpu().numpy()
             assert np.max(np.abs(md - mdg)) < 1e-8 * max(1.0, np.max(mdg)), (order, S, B)
             for b in sorted({0, B // 2, B - 1}):
                 ref, ref_md = oracle_mod.solve(order, wp[b], bc[b, [0, 1]], bc[b, [2, 3]], tm[b], pw, float(vw[b]))
-                assert synth.rel_err(a[b].reshape(1, -1), ref.reshape(1, -1)) < 1e-7, (order, S, B, b)
+                synth.parity_gate(a[b], ref, TOL_PEN, ("path kernel vs oracle", order, S, B, b))
                 assert abs(md[b] - ref_md) < 1e-7 * max(1.0, ref_md), (order, S, B, b)
         # batch-wide boundary conditions and weight, host-memory entry
         wp, tm = synth.make_batch(70, S, config_id=90 + order)
@@ -186,7 +195,7 @@ def test_path_penalty_register_kernel(csp, oracle_mod, order, S_list):
         r = csp.solve_batch(wp, tm, bc1, order=order, path_weight=0.3, vel_zero_weight=0.05, want_max_dev=True)
         assert r.kernel.startswith("fixedpath_")
         ref, ref_md = oracle_mod.solve_batch(order, wp, tm, bc1, path_weight=0.3, vel_zero_weight=0.05)
-        assert synth.rel_err(r.coeffs, ref) < 1e-7, (order, S)
+        synth.parity_gate(r.coeffs, ref, TOL_PEN, ("path kernel host entry vs oracle", order, S))
         assert np.max(np.abs(r.max_dev - ref_md)) < 1e-7 * max(1.0, np.max(ref_md))
 
 
@@ -311,7 +320,7 @@ def test_ragged_batch(csp, oracle_mod):
     for i, (o, w, t) in enumerate(trajs):
         ref, _ = oracle_mod.solve(4, w, np.zeros((2, 3)), np.zeros((2, 3)), t)
         got = r.coeffs[off[i]:off[i + 1]]
-        assert synth.rel_err(got.reshape(1, -1), ref.reshape(1, -1)) < TOL_WELL, i
+        synth.parity_gate(got, ref, TOL_WELL, ("ragged vs oracle", i))
 
 
 @pytest.mark.parametrize("span", [False, True])
@@ -323,7 +332,7 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order, span):
     17 segments with CSP_FLAG_SPAN), per-trajectory boundary conditions and weights."""
     import torch
     rng = np.random.default_rng(200 + order)
-    tol_g = 1e-6 if order == 5 else 1e-8
+    tol_g = TOL_KERNELS_O5_LONG if order == 5 else TOL_KERNELS
     classes = ((1, 4, 300), (1, 9, 257), (3, 16, 200), (5, 33, 150), (17, 64, 130), (60, 130, 40), (200, 256, 9))
     if span:
         classes = classes[3:] + ((1, 40, 333),)
@@ -352,14 +361,12 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order, span):
         assert not r.max_dev.cpu().numpy().any()
         a, gg = r.coeffs.cpu().numpy(), g.coeffs.cpu().numpy()
         for i in range(B):
-            e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), gg[off[i]:off[i + 1]].reshape(1, -1))
-            assert e < tol_g, (order, smax, i, int(S_b[i]), e)
+            synth.parity_gate(a[off[i]:off[i + 1]], gg[off[i]:off[i + 1]], tol_g, ("chunked/span vs generic", order, span, smax, i, int(S_b[i])))
         for i in sorted({0, B // 2, B - 1}):
             if (S_b[i] > 64 and order == 5) or S_b[i] > 260:
                 continue   # the dense oracle itself is ill-conditioned / too slow there
-            ref, _ = oracle_mod.solve(order, wps[i], bc[i, [0, 1]], bc[i, [2, 3]], tms[i], 0.0, float(vw[i]))
-            e = synth.rel_err(a[off[i]:off[i + 1]].reshape(1, -1), ref.reshape(1, -1))
-            assert e < (1e-5 if order == 5 else 1e-7), (order, smax, i, e)
+            ref, _ = oracle_mod.solve(order, wps[i], bc[i, [0, 1]], bc[i, [2, 3]], tms[i], 0.0, float(vw[i]), long_double=order == 5)
+            synth.parity_gate(a[off[i]:off[i + 1]], ref, NORTH_STAR_TOL if order == 5 else TOL_WELL, ("chunked/span vs oracle", order, span, smax, i))
     # uniform long trajectories, batch-wide boundary conditions, host-memory entry, fp64 and fp32 storage
     for S in (17, 32, 100):
         wp, tm = synth.make_batch(77, S, config_id=400 + order)
@@ -369,13 +376,13 @@ def test_chunked_kernel_ragged_and_long(csp, oracle_mod, order, span):
                             "span_o%d_f64_l%d" % (order, 2 if S <= 32 else 8)), r.kernel
         g = csp.solve_batch(wp, tm, bc1, order=order, vel_zero_weight=0.05, force_generic=True)
         assert not r.status.any()
-        assert synth.rel_err(r.coeffs, g.coeffs) < tol_g, (order, S)
+        synth.parity_gate(r.coeffs, g.coeffs, tol_g, ("chunked/span uniform vs generic", order, span, S))
         r32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05,
                               span=span)
         g32 = csp.solve_batch(wp.astype(np.float32), tm.astype(np.float32), bc1.astype(np.float32), order=order, vel_zero_weight=0.05, force_generic=True)
         assert r32.kernel.startswith("%s_o%d_f32io_f64_l" % ("span" if span else "chunked", order)), r32.kernel
         assert r32.coeffs.dtype == np.float32
-        assert synth.rel_err(r32.coeffs, g32.coeffs) < 1e-6, (order, S)
+        synth.parity_gate(r32.coeffs, g32.coeffs, 1e-6, ("chunked/span f32 storage vs generic", order, span, S))
 
 
 def test_chunked_kernel_status(csp):
