@@ -75,6 +75,80 @@ template <int O, int S> constexpr bool path_dense = (O == 2 && S >= 8);
 // doubles per staging row: the dense variant gives up the two padding doubles (2-way conflicts on its six
 // ds_write_b128 per segment, a few dozen clocks) for 2 KB of LDS
 template <int O, int S> constexpr int path_stage_row = path_dense<O, S> ? FixedLds<O, S>::REC : FixedLds<O, S>::STAGE_ROW;
+// Dense residency WITH whole-line stores (round 3; order 2, S = 8, 12, 16 -- trajectories that start on lines): a
+// 64-row ring tile does not fit under 40 KB, so the tile has 32 rows and a segment's records leave in two half-wave
+// phases (HalfRing below); the bytes a phase would have to keep in the tile for the next record are kept in REGISTERS
+// instead (they are part of the previous record, which the lane still holds) and re-written with it.
+template <int O, int S> constexpr bool path_dense_ring = path_dense<O, S> && LineGeom<O, S>::OK;
+template <int O, int S> constexpr int path_tile_doubles = path_dense_ring<O, S> ? 32 * 26 : 64 * path_stage_row<O, S>;
+
+// Half-height ring of the dense order-2 kernel: rows of 192 ring bytes (+ 16 bytes of padding: the stride in dwords is an
+// odd multiple of 4), 32 rows.  A 128-byte line that starts at ring byte 128 wraps (pieces 4..7 sit at ring bytes 0..63).
+template <int S, bool BOTTOM> struct HalfRing {
+    static constexpr int RECB = 96, RINGB = 192, ROW = 26, HT = (S + 1) / 2, RS = S * RECB;
+    static constexpr int LO = BOTTOM ? HT * RECB : 0, HI = BOTTOM ? S * RECB : HT * RECB;
+    __device__ static __forceinline__ constexpr int pos(int x) { return (x % RINGB) / 8; }   // doubles
+    // One segment's records of the slice: cn = this lane's new record (12 doubles, [axis][power]), cp = its previous one
+    // (segment g+1 for the top role, g-1 for the bottom role; unused at the role's first record).
+    __device__ static __forceinline__ void put_and_flush(int g, const double (&cn)[12], const double (&cp)[12], double *tile, char *tbase,
+                                                         int lane, bool nt, unsigned live8) {
+        const int rlo = g * RECB, rhi = rlo + RECB;
+        constexpr int C128 = 128;
+        // bytes of the previous record that still wait for their line
+        const int hlo = BOTTOM ? ((rlo / C128) * C128 > LO ? (rlo / C128) * C128 : LO) : rhi;
+        const int hhi = BOTTOM ? rlo : ((((rhi + 127) / C128) * C128) < HI ? (((rhi + 127) / C128) * C128) : HI);
+        const int prlo = BOTTOM ? rlo - RECB : rhi;     // where the previous record starts
+        const int l0 = BOTTOM ? rlo / C128 : (rlo + 127) / C128;
+        const int nl = BOTTOM ? rhi / C128 - rlo / C128 : (rhi + 127) / C128 - (rlo + 127) / C128;   // 0 or 1
+        const int q = lane >> 3, p = lane & 7;
+        const int row32 = lane & 31;
+        const unsigned g_lane = (unsigned)(q * RS + p * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((lane >> 5) == h) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (prlo + 16 * k >= hlo && prlo + 16 * k + 16 <= hhi) {
+                        double2 v2;
+                        v2.x = cp[2 * k];
+                        v2.y = cp[2 * k + 1];
+                        *reinterpret_cast<double2 *>(tile + row32 * ROW + pos(prlo + 16 * k)) = v2;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    double2 v2;
+                    v2.x = cn[2 * k];
+                    v2.y = cn[2 * k + 1];
+                    *reinterpret_cast<double2 *>(tile + row32 * ROW + pos(rlo + 16 * k)) = v2;
+                }
+            }
+            // Half the lanes wrote, all lanes read: the exchange crosses lanes THROUGH a divergent branch.  Per thread the
+            // reads below do not depend on the (not taken) writes, so without a CONVERGENT marker the compiler may duplicate
+            // the tail into both sides of the branch and run the non-writers' reads first (it did: rows 32..35 of every
+            // slice read the other half's bytes).  wave_barrier is convergent; the fences pin the memory order around it.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (nl > 0) {
+                const int ell = l0;
+                const bool whole = BOTTOM ? ell * 128 >= LO : ell * 128 + 128 <= HI;
+                const bool pv = whole || (BOTTOM ? ell * 128 + p * 16 >= LO : ell * 128 + p * 16 < HI);
+                const int c = (ell * 128) % RINGB;                        // 0, 64 or 128
+                const int poff = c == 128 ? (p < 4 ? 16 + p * 2 : (p - 4) * 2) : c / 8 + p * 2;
+                double2 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2 *>(tile + (i * 8 + q) * ROW + poff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (pv && ((live8 >> (h * 4 + i)) & 1u)) store16(tbase + ell * 128 + (size_t)(h * 32 + i * 8) * RS + g_lane, v[i], nt);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane has read before the other half overwrites the tile
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+};
 
 // Dense residency: a role's segment times live in registers for the whole kernel (waypoints still come from LDS), so
 // that the staging tiles can lie on top of the LDS image of the times.
@@ -245,9 +319,11 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
     // whole-line stores through the ring of minsnap_fixed_impl.h (LineRing) wherever the trajectories start on 128-byte
     // lines; the dense order-2 variant keeps its 96-byte tile rows (no room for a ring under 40 KB of LDS)
     constexpr bool RING = PEN && LineGeom<O, S>::OK && !path_dense<O, S>;
+    constexpr bool DRING = PEN && path_dense_ring<O, S>;   // order 2 only: half-height ring, records held in registers
     using LR = LineRing<O, S, BOTTOM>;
+    double cprev[DRING ? 12 : 1] = {};
     unsigned live8 = 0;   // bit i: row i*8 + lane/8 is a live trajectory of this slice
-    if (RING) {
+    if (RING || DRING) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = i * 8 + (lane >> 3);
@@ -372,6 +448,7 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
         } else {
             const int g = BOTTOM ? S - 1 - j : j;
             double d2 = 0.0, len2 = 0.0;
+            double cnew[DRING ? 12 : 1];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 double xs[N], xe[N], c[M];
@@ -383,13 +460,18 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 }
                 const double Ps = BOTTOM ? P1[ax] : P0[ax], Pe = BOTTOM ? P0[ax] : P1[ax];
                 recover<O>(Ps, Pe - Ps, xs, xe, tp, ip, c);
+                if constexpr (DRING) {
 #pragma unroll
-                for (int i = 0; i < M; i += 2) {
-                    double2 v2;
-                    v2.x = c[i];
-                    v2.y = c[i + 1];
-                    const int at = RING ? LR::pos(g * RECB + (ax * M + i) * 8) : ax * M + i;
-                    *reinterpret_cast<double2 *>(stage + lane * ROW + at) = v2;
+                    for (int i = 0; i < M; ++i) cnew[ax * M + i] = c[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < M; i += 2) {
+                        double2 v2;
+                        v2.x = c[i];
+                        v2.y = c[i + 1];
+                        const int at = RING ? LR::pos(g * RECB + (ax * M + i) * 8) : ax * M + i;
+                        *reinterpret_cast<double2 *>(stage + lane * ROW + at) = v2;
+                    }
                 }
                 if (STATUS) {
                     // Non-finite values are caught on the highest-power and the constant coefficient: every endpoint
@@ -438,7 +520,12 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
                 maxdev = ratio > maxdev ? ratio : maxdev;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (RING) {
+            if constexpr (DRING) {
+                HalfRing<S, BOTTOM>::put_and_flush(g, cnew, cprev, stage, reinterpret_cast<char *>((double *)a.coeffs + b0 * S * L::REC), lane,
+                                                   a.nt_stores != 0, live8);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) cprev[i] = cnew[i];
+            } else if (RING) {
                 LR::template flush<true>(g, stage, reinterpret_cast<char *>((double *)a.coeffs + b0 * S * L::REC), lane, a.nt_stores != 0, live8);
             } else {
                 char *gbase = reinterpret_cast<char *>((double *)a.coeffs + (b0 * S + g) * L::REC);
@@ -526,17 +613,20 @@ minsnap_fixed_path_kernel(GenericArgs a) {
     // CU = two waves per SIMD (the order-2 sweep fits 256 registers once its segments are separate basic blocks),
     // and the 1024 workgroups of a 65536-trajectory batch are resident at once.
     constexpr bool DENSE = path_dense<O, S>;
-    constexpr int TILE = 64 * path_stage_row<O, S>;
+    constexpr int TILE = path_tile_doubles<O, S>;
     static_assert(L::CARRY * 64 <= TILE, "carries must fit in a staging tile");
     static_assert(!DENSE || 64 * S <= 2 * TILE, "the image of the times must fit under the staging tiles");
-    __shared__ __attribute__((aligned(16))) double lds[L::WP_DOUBLES + (DENSE ? 0 : 64 * S) + 2 * TILE + 17 * M + 64 + 64];
+    // DENSE: the end-of-kernel hand-over of max_dev / status bits (l_dev, l_bits) lies on the top role's tile, which is
+    // dead by then (both waves have passed a barrier after their last staged store)
+    static_assert(!DENSE || 64 + 32 <= TILE, "l_dev + l_bits must fit in a staging tile");
+    __shared__ __attribute__((aligned(16))) double lds[L::WP_DOUBLES + (DENSE ? 0 : 64 * S) + 2 * TILE + 17 * M + (DENSE ? 0 : 64) + (DENSE ? 32 : 64)];
     double *l_wp = lds;
     double *l_tm = l_wp + L::WP_DOUBLES;
     double *l_stage = DENSE ? l_tm : l_tm + 64 * S;
     double *l_hw = l_stage + 2 * TILE;
-    double *l_dev = l_hw + 17 * M;
-    int *l_skip = reinterpret_cast<int *>(l_dev + 64);
-    int *l_bits = l_skip + 64;
+    double *l_dev = DENSE ? l_stage : l_hw + 17 * M;
+    int *l_skip = reinterpret_cast<int *>(DENSE ? l_hw + 17 * M : l_dev + 64);
+    int *l_bits = DENSE ? reinterpret_cast<int *>(l_stage + 64) : l_skip + 64;
     const int tid = threadIdx.x, lane = tid & 63, role = tid >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
@@ -625,7 +715,7 @@ template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream
     const bool big = (double)a.B * S * 6 * O * 8.0 >= 48.0 * 1024 * 1024;
     // Round 3: orders 2 / 3 store whole lines too (LineRing) where the trajectories start on lines -- except the dense
     // order-2 variant -- and take the same rule.
-    constexpr bool WHOLE_LINES = O == 4 || (LineGeom<O, S>::OK && !path_dense<O, S>);
+    constexpr bool WHOLE_LINES = O == 4 || LineGeom<O, S>::OK;   // incl. the dense order-2 variant (HalfRing)
     f.nt_stores = nt_forced() >= 0 ? nt_forced() : (WHOLE_LINES && big ? 1 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);

@@ -135,5 +135,5 @@ def test_path_kernel_whole_line_stores_and_the_skip_mask(csp, oracle_mod, order,
         n_loop += int(it[b] > 0)
         assert abs(vwo[b] - info["vel_zero_weight"]) <= 1e-15
         assert abs(md[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
-        synth.parity_gate(co[b], info["coeff"], 1e-7, ("path ring stores, loop, vs oracle", order, S, b))
+        synth.parity_gate(co[b], info["coeff"], 1e-6, ("path ring stores, loop, vs oracle", order, S, b))
     assert n_loop > 0 and (it[:64] == 0).all()
