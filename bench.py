@@ -117,15 +117,17 @@ def bench_uniform(csp, dev, B, S, o, steps, warmup, config_id, pw=0.0, vw=0.0, l
 
 
 def bench_c5(csp, dev, batch, steps, warmup):
-    """BASELINE config C5 -- mixed batch, S ~ U{4..64}, order ~ U{3,4,5}, fp32 storage, bucketed by order and length
-    class on the host BEFORE the timed region (cs-pathplan_amd/mixed.py)."""
+    """BASELINE config C5 -- mixed batch, S ~ U{4..64}, order ~ U{3,4,5}, fp32 storage -- through ONE csp_minsnap_solve_mixed call
+    per step: the bucketing by (order, length class) runs on the device INSIDE the timed region, and the coefficients land in
+    the caller's order (no un-permute exists to be left out)."""
     trajs = synth.make_ragged(batch)
     mixed = _load_mixed(csp)
     plan = mixed.MixedBatch(csp, trajs, dev, dtype=torch.float32)
     ms = timed(plan.run, steps, warmup, dev)
-    return {"workload": "C5 mixed ragged: S~U{4..64}, order~U{3,4,5}, fp32 storage / fp64 arithmetic", "batch": batch,
-            "launches_per_step": plan.launches, "kernels": plan.kernels, "kernel_ms": ms,
-            "solves_per_s": batch / (ms * 1e-3), "algorithmic_bytes_per_launch": plan.algorithmic_bytes,
+    return {"workload": "C5 mixed ragged: S~U{4..64}, order~U{3,4,5}, fp32 storage / fp64 arithmetic; one csp_minsnap_solve_mixed call per "
+                        "step, device-side bucketing (histogram, scan, scatter) and caller-order output INCLUDED in the timed region",
+            "batch": batch, "launches_per_step": "3 bucketing kernels + one persistent launch per order", "kernels": plan.kernels,
+            "kernel_ms": ms, "solves_per_s": batch / (ms * 1e-3), "algorithmic_bytes_per_launch": plan.algorithmic_bytes,
             "achieved_GBps": plan.algorithmic_bytes / (ms * 1e-3) / 1e9,
             "frac_of_hbm_peak": plan.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": steps}
 

@@ -36,10 +36,11 @@ FLAG_NO_PERSISTENT = 0x4
 FLAG_F32_ARITH = 0x8
 FLAG_LONG_SEGMENTS = 0x10
 FLAG_SPAN = 0x20
-TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD = 0, 1, 2
+TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD, TRAJ_SKIPPED = 0, 1, 2, 4
 
 EXPORTED_SYMBOLS = (
     "csp_minsnap_solve_batch", "csp_minsnap_solve_batch_sharded", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
+    "csp_minsnap_solve_mixed", "csp_minsnap_mixed_workspace_bytes",
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_generate_batch", "csp_minsnap_sample_capacity",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
@@ -83,6 +84,10 @@ _lib.csp_minsnap_solve_batch_sharded.restype = ctypes.c_int
 _lib.csp_minsnap_solve_batch_sharded.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
 _lib.csp_minsnap_workspace_bytes.restype = ctypes.c_size_t
 _lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
+_lib.csp_minsnap_solve_mixed.restype = ctypes.c_int
+_lib.csp_minsnap_solve_mixed.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p]
+_lib.csp_minsnap_mixed_workspace_bytes.restype = ctypes.c_size_t
+_lib.csp_minsnap_mixed_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
 _lib.csp_minsnap_time_alloc_batch.restype = ctypes.c_int
 _lib.csp_minsnap_time_alloc_batch.argtypes = [ctypes.POINTER(Desc), ctypes.c_void_p, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
@@ -296,6 +301,95 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
             None, 0, None)
     _check(rc)
     return Result(out, md, stt, kernel_name(desc))
+
+
+class MixedResult:
+    """coeffs: flat storage-dtype array, trajectory b's [S_b,3,2*order_b] block at coeff_offsets[b] .. coeff_offsets[b+1]."""
+    def __init__(self, coeffs, coeff_offsets, status):
+        self.coeffs, self.coeff_offsets, self.status = coeffs, coeff_offsets, status
+
+
+def mixed_coeff_total(orders, seg_offsets):
+    """Elements of the tightly concatenated coefficient array of a mixed batch: sum_b 6 * order_b * S_b (host or device)."""
+    if _is_torch(seg_offsets):
+        return int(((seg_offsets[1:] - seg_offsets[:-1]) * 6 * orders.to(seg_offsets.dtype)).sum().item())
+    return int(np.sum(np.diff(np.asarray(seg_offsets, dtype=np.int64)) * 6 * np.asarray(orders, dtype=np.int64)))
+
+
+class PreparedMixed:
+    """csp_minsnap_solve_mixed with descriptor, buffers and workspace fixed: `run()` is ONE C-ABI call that buckets the batch
+    by (order, length class) on the device and solves it, coefficients in the caller's order (include/csp_minsnap.h)."""
+
+    def __init__(self, orders, waypoints, times, seg_offsets, bc=None, vel_zero_weight=0.0, max_segments=None, out=None,
+                 want_status=False, stream=None):
+        import torch
+        if not (_is_torch(waypoints) and waypoints.is_cuda):
+            raise ValueError("PreparedMixed takes CUDA tensors (device memory space)")
+        self.dev, tdt = waypoints.device, waypoints.dtype
+        dtype = DTYPE_F32 if tdt == torch.float32 else DTYPE_F64
+        self.wp, self.tm = waypoints.contiguous(), times.to(tdt).contiguous()
+        self.off = seg_offsets.to(device=self.dev, dtype=torch.int64).contiguous()
+        self.orders = orders.to(device=self.dev, dtype=torch.int32).contiguous()
+        B = self.off.numel() - 1
+        if max_segments is None:
+            max_segments = int((self.off[1:] - self.off[:-1]).max().item()) if B else 1
+        self.bc = (torch.zeros((1, 4, 3), dtype=tdt, device=self.dev) if bc is None else bc.to(tdt).contiguous().reshape(-1, 4, 3))
+        self.total = mixed_coeff_total(self.orders, self.off)
+        self.out = out if out is not None else torch.empty(max(self.total, 1), dtype=tdt, device=self.dev)
+        self.coeff_offsets = torch.empty(B + 1, dtype=torch.int64, device=self.dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=self.dev) if want_status else None
+        self.desc = make_desc(0, B, 0, dtype, 0.0, vel_zero_weight, MEM_DEVICE, self.bc.shape[0] == B and B != 1,
+                              seg_offsets_ptr=self.off.data_ptr(), max_segments=max_segments,
+                              device_id=self.dev.index if self.dev.index is not None else -1, flags=0)
+        self.ws_bytes = _lib.csp_minsnap_mixed_workspace_bytes(ctypes.byref(self.desc))
+        self.ws = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=self.dev)
+        self._stream = stream
+        self._args = (ctypes.byref(self.desc), self.orders.data_ptr(), self.wp.data_ptr(), self.tm.data_ptr(), self.bc.data_ptr(),
+                      self.out.data_ptr(), self.coeff_offsets.data_ptr(), self.status.data_ptr() if want_status else None,
+                      self.ws.data_ptr(), self.ws_bytes)
+
+    def run(self, stream=None):
+        import torch
+        st = stream if stream is not None else (self._stream if self._stream is not None
+                                                else torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = _lib.csp_minsnap_solve_mixed(*self._args, ctypes.c_void_p(st))
+        if rc:
+            _check(rc)
+        return self.out
+
+
+def solve_mixed(orders, waypoints, times, seg_offsets, bc=None, vel_zero_weight=0.0, vel_zero_weight_per_traj=None,
+                max_segments=None, want_status=False, stream=None):
+    """csp_minsnap_solve_mixed: a ragged batch whose trajectories carry their own derivative order (2..5).
+    numpy inputs -> CSP_MEM_HOST, torch CUDA tensors -> CSP_MEM_DEVICE.  Returns MixedResult."""
+    if _is_torch(waypoints):
+        import torch
+        if vel_zero_weight_per_traj is not None:
+            raise ValueError("per-trajectory weights: use the host-memory form or PreparedMixed")
+        p = PreparedMixed(orders, waypoints, times, seg_offsets, bc, vel_zero_weight, max_segments, want_status=want_status, stream=stream)
+        p.run()
+        return MixedResult(p.out, p.coeff_offsets, p.status)
+    waypoints = np.asarray(waypoints)
+    dtype = DTYPE_F32 if waypoints.dtype == np.float32 else DTYPE_F64
+    npdt = _np_dtype(dtype)
+    waypoints = np.ascontiguousarray(waypoints, dtype=npdt)
+    times = np.ascontiguousarray(times, dtype=npdt)
+    seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.int64)
+    orders = np.ascontiguousarray(orders, dtype=np.int32)
+    B = seg_offsets.shape[0] - 1
+    if max_segments is None:
+        max_segments = int(np.max(np.diff(seg_offsets))) if B else 1
+    bc = np.zeros((1, 4, 3), dtype=npdt) if bc is None else np.ascontiguousarray(bc, dtype=npdt).reshape(-1, 4, 3)
+    out = np.empty(max(mixed_coeff_total(orders, seg_offsets), 1), dtype=npdt)
+    cof = np.empty(B + 1, dtype=np.int64)
+    stt = np.empty(B, dtype=np.int32) if want_status else None
+    vwp = np.ascontiguousarray(vel_zero_weight_per_traj, dtype=np.float64) if vel_zero_weight_per_traj is not None else None
+    desc = make_desc(0, B, 0, dtype, 0.0, vel_zero_weight, MEM_HOST, bc.shape[0] == B and B != 1, seg_offsets.ctypes.data, max_segments,
+                     vwp.ctypes.data if vwp is not None else None, -1, 0)
+    rc = _lib.csp_minsnap_solve_mixed(ctypes.byref(desc), orders.ctypes.data, waypoints.ctypes.data, times.ctypes.data, bc.ctypes.data,
+                                      out.ctypes.data, cof.ctypes.data, stt.ctypes.data if stt is not None else None, None, 0, None)
+    _check(rc)
+    return MixedResult(out, cof, stt)
 
 
 class PreparedSolve:

@@ -289,6 +289,74 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
     return CSP_OK;
 }
 
+size_t csp_minsnap_mixed_workspace_bytes(const csp_minsnap_desc *desc) {
+    if (!desc || desc->batch < 0) return 0;
+    return csp::mixed_workspace_bytes(desc->batch);
+}
+
+int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders, const void *waypoints, const void *times,
+                            const void *bc, void *coeffs, int64_t *coeff_offsets_out, int32_t *status,
+                            void *workspace, size_t workspace_bytes, void *hip_stream) {
+    if (!desc || desc->abi_version != CSP_MINSNAP_ABI_VERSION) return CSP_ERR_INVALID_ARG;
+    if (desc->dtype != CSP_DTYPE_F64 && desc->dtype != CSP_DTYPE_F32) return CSP_ERR_INVALID_ARG;
+    if (desc->mem_space != CSP_MEM_HOST && desc->mem_space != CSP_MEM_DEVICE) return CSP_ERR_INVALID_ARG;
+    if (desc->batch < 0 || desc->vel_zero_weight < 0.0 || desc->path_weight < 0.0) return CSP_ERR_INVALID_ARG;
+    if (desc->path_weight != 0.0 || (desc->flags & (CSP_FLAG_F32_ARITH | CSP_FLAG_SEGMENT_MAJOR))) return CSP_ERR_UNSUPPORTED;
+    if (desc->batch == 0) return CSP_OK;
+    if (desc->batch > 0x7fffffff) return CSP_ERR_INVALID_ARG;   // trajectory indices are int32 on the device
+    if (!desc->seg_offsets || desc->max_segments < 1 || desc->max_segments > 256) return CSP_ERR_INVALID_ARG;
+    if (!orders || !waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
+    int rc = select_device(desc->device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool f32 = desc->dtype == CSP_DTYPE_F32;
+    const size_t elt = f32 ? 4 : 8;
+    const int64_t B = desc->batch;
+    const size_t need = csp::mixed_workspace_bytes(B);
+    csp::GenericArgs a;
+    a.max_dev = nullptr; a.ws = nullptr; a.tstar = nullptr;
+    a.path_weight = 0.0;
+    a.vel_zero_weight = desc->vel_zero_weight;
+    a.B = B; a.S = 0; a.order = 0; a.bc_per_traj = desc->bc_per_trajectory ? 1 : 0;
+    a.seg_major = 0; a.Btotal = B; a.Boffset = 0; a.persistent = 1; a.skip = nullptr; a.tau_mode = 0;
+    if (desc->mem_space == CSP_MEM_DEVICE) {
+        if (!workspace || workspace_bytes < need) return CSP_ERR_WORKSPACE;
+        if (((uintptr_t)coeffs & 15u) || ((uintptr_t)workspace & 15u)) return CSP_ERR_INVALID_ARG;
+        a.wp = waypoints; a.times = times; a.bc = bc; a.coeffs = coeffs; a.status = status;
+        a.seg_off = desc->seg_offsets; a.vw_per = desc->vel_zero_weight_per_traj;
+        hipError_t e = csp::launch_mixed(a, f32, orders, workspace, coeff_offsets_out, st);
+        return e == hipSuccess ? CSP_OK : hip_fail(e, "mixed launch");
+    }
+    // CSP_MEM_HOST: sizes from the caller's host arrays, staging through the cached arena, synchronous
+    const int64_t total_seg = desc->seg_offsets[B];
+    size_t total_co = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t n = desc->seg_offsets[b + 1] - desc->seg_offsets[b];
+        if (n < 0 || n > desc->max_segments) return CSP_ERR_INVALID_ARG;
+        if (orders[b] >= 1) total_co += (size_t)n * 6 * (size_t)orders[b];
+    }
+    csp::HostCall hc(current_device(), st);
+    const size_t o_wp = hc.in(waypoints, (size_t)(total_seg + B) * 3 * elt), o_tm = hc.in(times, (size_t)total_seg * elt);
+    const size_t o_bc = hc.in(bc, (size_t)(desc->bc_per_trajectory ? B : 1) * 12 * elt);
+    const size_t o_so = hc.in(desc->seg_offsets, (size_t)(B + 1) * 8), o_or = hc.in(orders, (size_t)B * 4);
+    const size_t o_vw = desc->vel_zero_weight_per_traj ? hc.in(desc->vel_zero_weight_per_traj, (size_t)B * 8) : 0;
+    const size_t o_co = hc.out(coeffs, total_co * elt);
+    const size_t o_cf = coeff_offsets_out ? hc.out(coeff_offsets_out, (size_t)(B + 1) * 8) : 0;
+    const size_t o_st = status ? hc.out(status, (size_t)B * 4) : 0;
+    const size_t o_ws = hc.scratch(need);
+    CSP_HIP(hc.upload());
+    a.wp = hc.ptr(o_wp); a.times = hc.ptr(o_tm); a.bc = hc.ptr(o_bc); a.coeffs = hc.ptr(o_co);
+    a.status = status ? hc.ptr<int32_t>(o_st) : nullptr;
+    a.seg_off = hc.ptr<const int64_t>(o_so);
+    a.vw_per = desc->vel_zero_weight_per_traj ? hc.ptr<const double>(o_vw) : nullptr;
+    // skipped trajectories leave their block untouched: the caller's bytes must survive the round trip
+    CSP_HIP(hipMemsetAsync(hc.ptr(o_co), 0, total_co * elt, st));
+    hipError_t e = csp::launch_mixed(a, f32, hc.ptr<const int32_t>(o_or), hc.ptr(o_ws), coeff_offsets_out ? hc.ptr<int64_t>(o_cf) : nullptr, st);
+    if (e != hipSuccess) return hip_fail(e, "mixed launch");
+    CSP_HIP(hc.download());
+    return CSP_OK;
+}
+
 int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                                     const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu) {
     Shape s;

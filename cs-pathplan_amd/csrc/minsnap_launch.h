@@ -53,6 +53,13 @@ bool chunked_supported(int order, int Smax, bool f32_arith, double path_weight, 
 int chunked_lanes_log2(int Smax);
 hipError_t launch_chunked(const GenericArgs &a, bool f32, int Smax, hipStream_t st);
 
+// Mixed-ORDER ragged batches (minsnap_mixed.hip): device-side bucketing by (order, length class), one persistent launch per
+// order, inputs read and coefficients written in the caller's order.  a.seg_off, a.B, a.wp/times/bc/coeffs/status, a.vw_per
+// and the weights are used; `orders` is [B] int32 on the device; `workspace` >= mixed_workspace_bytes(B); coef_off_out:
+// optional [B+1] int64 (element offsets of every trajectory's coefficient block).
+size_t mixed_workspace_bytes(int64_t B);
+hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, void *workspace, int64_t *coef_off_out, hipStream_t st);
+
 // Long trajectories (16 < S <= 1024): spans of 16 segments per lane, recovery by recomputation
 // (minsnap_span.hip); same options as the chunked kernel.
 bool span_supported(int order, int Smax, bool f32_arith, double path_weight, bool seg_major);

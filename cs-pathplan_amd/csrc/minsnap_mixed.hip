@@ -1,0 +1,319 @@
+// minsnap_mixed.hip -- mixed-ORDER ragged batches in one call (BASELINE config 5: per-trajectory segment count and
+// derivative order; csp_minsnap_solve_mixed, include/csp_minsnap.h).  Everything happens on the device and in the
+// caller's own order -- no gather, no un-permute:
+//
+//   1. bucketing (three small kernels): every trajectory gets the key (order, length class) -- the length class is the
+//      number of lanes the workspace-free kernel gives a trajectory (minsnap_chunked_impl.h: 4 segments per lane, rounded
+//      up to a power of two) --; a histogram, an exclusive scan of the coefficient sizes 6 * order * S in CALLER order
+//      (= where each trajectory's block starts in `coeffs`) and a scatter of the trajectory indices into bucket order
+//      (`perm`, longest class first inside an order);
+//   2. one PERSISTENT launch per derivative order (the register budgets differ: 190 / 256 / 392 VGPRs at orders 3 / 4 /
+//      5, so one kernel for all would run everything at one wave per SIMD): wave w takes the work units w, w + grid, ...
+//      of its order -- a unit = 64 lanes of one length class --, reading the inputs and writing the coefficients of
+//      trajectory perm[k] in place.  The launches of the orders run concurrently on forked streams.
+//
+// The reference has no batched entry at all (one flight per call, uavPathPlanning.cpp:4423, :4461); per trajectory the
+// arithmetic is that of csp_minsnap_solve_batch on the same order and length class (bit-equal: tests/test_gpu_round3.py).
+#include "minsnap_chunked_impl.h"
+#include "minsnap_mixed.h"
+
+namespace csp {
+namespace mixed {
+
+constexpr int NCLS = 7;          // lanes per trajectory 64, 32, .., 1 (class k <-> lpt_log2 = 6 - k): longest first
+constexpr int NORD = 4;          // orders 2..5
+constexpr int ITEMS = 4;         // trajectories per thread of the bucketing kernels
+constexpr int BT = 256;          // threads per bucketing block
+
+__device__ __forceinline__ int lanes_log2(int S) {   // chunked_lanes_log2 on the device: 4 segments per lane
+    int l = 0;
+    while ((chunked::CMAX << l) < S) ++l;
+    return l;
+}
+
+// key = order index * NCLS + class, or -1 for a trajectory this path does not serve (order outside 2..5, S outside 1..256)
+__device__ __forceinline__ int key_of(int order, int64_t S) {
+    if (order < 2 || order > 5 || S < 1 || S > chunked::CMAX * 64) return -1;
+    return (order - 2) * NCLS + (6 - lanes_log2((int)S));
+}
+
+// No global atomics anywhere in the bucketing: same-address device-scope atomics cost ~60 ns EACH on this part (measured:
+// a first version whose persistent waves pulled work units from one counter spent 1.2 ms on 20 k atomicAdds, whatever
+// the work), so blocks publish their histograms and the planning block turns them into per-block offsets.
+__global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, int32_t *hist_blk, int64_t *block_sum) {
+    __shared__ int hist[NORD * NCLS];
+    __shared__ long long wsum[BT / 64];
+    const int tid = threadIdx.x;
+    if (tid < NORD * NCLS) hist[tid] = 0;
+    __syncthreads();
+    long long csz = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t i = ((int64_t)blockIdx.x * ITEMS + it) * BT + tid;
+        if (i < B) {
+            const int o = orders[i];
+            const int64_t S = seg_off[i + 1] - seg_off[i];
+            const int k = key_of(o, S);
+            if (k >= 0) atomicAdd(&hist[k], 1);
+            // the coefficient block exists in the caller's layout whether or not the trajectory is served
+            csz += (o >= 1 && S > 0) ? (long long)S * 6 * o : 0;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) csz += __shfl_xor(csz, d);
+    if ((tid & 63) == 0) wsum[tid >> 6] = csz;
+    __syncthreads();
+    if (tid < NORD * NCLS) hist_blk[(int64_t)blockIdx.x * (NORD * NCLS) + tid] = hist[tid];
+    if (tid == 0) {
+        long long s = 0;
+        for (int w = 0; w < BT / 64; ++w) s += wsum[w];
+        block_sum[blockIdx.x] = s;
+    }
+}
+
+// one block: bucket starts / work units per order, exclusive scan of the per-block coefficient sizes
+__global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist_blk, int64_t *block_sum, int64_t nblk, int64_t *coef_off, int64_t B) {
+    __shared__ long long carry;
+    __shared__ long long wtot[BT / 64];
+    __shared__ int total[NORD * NCLS];
+    const int tid = threadIdx.x;
+    // per key: exclusive scan over the blocks of that key's counts (in place: hist_blk becomes the block's offset inside its
+    // bucket); loads batched eight at a time
+    if (tid < NORD * NCLS) {
+        int run = 0;
+        for (int64_t b0 = 0; b0 < nblk; b0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = b0 + q < nblk ? hist_blk[(b0 + q) * (NORD * NCLS) + tid] : 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (b0 + q < nblk) hist_blk[(b0 + q) * (NORD * NCLS) + tid] = run;
+                run += v[q];
+            }
+        }
+        total[tid] = run;
+        tab->count[tid] = run;
+    }
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int start = 0;
+        for (int o = 0; o < NORD; ++o) {
+            int units = 0;
+            for (int k = 0; k < NCLS; ++k) {
+                const int n = total[o * NCLS + k];
+                tab->bucket_start[o][k] = start;
+                tab->unit_start[o][k] = units;
+                const int per_wave = 64 >> (6 - k);                  // trajectories per 64-lane work unit
+                units += (n + per_wave - 1) / per_wave;
+                start += n;
+            }
+            tab->bucket_start[o][NCLS] = start;
+            tab->unit_start[o][NCLS] = units;
+        }
+        tab->served = start;
+    }
+    // exclusive scan of block_sum, BT entries per round
+    for (int64_t base = 0; base < nblk; base += BT) {
+        const int64_t i = base + tid;
+        long long v = i < nblk ? block_sum[i] : 0, x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long y = __shfl_up(x, d);
+            if ((tid & 63) >= d) x += y;
+        }
+        if ((tid & 63) == 63) wtot[tid >> 6] = x;
+        __syncthreads();
+        long long pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w) pre += wtot[w];
+        if (i < nblk) block_sum[i] = pre + x - v;
+        __syncthreads();
+        if (tid == BT - 1) carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) coef_off[B] = carry;
+}
+
+__global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, const MixedTable *tab,
+                                                     const int32_t *blk_base, const int64_t *block_pre, int64_t *coef_off, int32_t *perm,
+                                                     int32_t *status) {
+    __shared__ int hist[NORD * NCLS], base[NORD * NCLS];
+    __shared__ long long wtot[BT / 64];
+    const int tid = threadIdx.x;
+    if (tid < NORD * NCLS) hist[tid] = 0;
+    __syncthreads();
+    int key[ITEMS], rank[ITEMS];
+    long long csz[ITEMS], mine = 0;
+    // thread t owns the ITEMS consecutive trajectories (blk * BT + t) * ITEMS .. : the scan of the coefficient sizes is in
+    // caller order
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t i = ((int64_t)blockIdx.x * BT + tid) * ITEMS + it;
+        key[it] = -1;
+        csz[it] = 0;
+        rank[it] = 0;
+        if (i < B) {
+            const int o = orders[i];
+            const int64_t S = seg_off[i + 1] - seg_off[i];
+            key[it] = key_of(o, S);
+            csz[it] = (o >= 1 && S > 0) ? (long long)S * 6 * o : 0;
+            if (key[it] >= 0) rank[it] = atomicAdd(&hist[key[it]], 1);
+            if (status) status[i] = key[it] >= 0 ? 0 : CSP_TRAJ_SKIPPED_BIT;   // the solve kernels OR their bits in
+        }
+        mine += csz[it];
+    }
+    long long x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long y = __shfl_up(x, d);
+        if ((tid & 63) >= d) x += y;
+    }
+    if ((tid & 63) == 63) wtot[tid >> 6] = x;
+    __syncthreads();
+    if (tid < NORD * NCLS) base[tid] = blk_base[(int64_t)blockIdx.x * (NORD * NCLS) + tid];
+    long long pre = block_pre[blockIdx.x] + x - mine;
+    for (int w = 0; w < (tid >> 6); ++w) pre += wtot[w];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t i = ((int64_t)blockIdx.x * BT + tid) * ITEMS + it;
+        if (i < B) {
+            coef_off[i] = pre;
+            pre += csz[it];
+            if (key[it] >= 0) {
+                const int o = key[it] / NCLS, k = key[it] - o * NCLS;
+                perm[tab->bucket_start[o][k] + base[key[it]] + rank[it]] = (int32_t)i;
+            }
+        }
+    }
+}
+
+// Persistent solve of ONE order's buckets: wave w of the grid takes the work units w, w + gridDim.x, ... of this order (a
+// unit = 64 lanes of one length class; the list runs longest class first, so the strided deal is balanced) -- a fixed trip
+// count every wave reaches, no work counter (see count_kernel for what one costs).
+template <int O, typename IO, bool STATUS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(O <= 4 ? 2 : 1)))
+minsnap_chunked_mixed_kernel(GenericArgs a, const int32_t *perm, const int64_t *coef_off, const MixedTable *tab) {
+    using IL = iface::IfaceLds<O>;
+    __shared__ double lds[IL::ENTRIES * 64];
+    __shared__ double xch[3 * (O - 1) * 64];
+    const int lane = threadIdx.x;
+    constexpr int oi = O - 2;
+    int ustart[NCLS + 1], bstart[NCLS + 1];
+#pragma unroll
+    for (int k = 0; k <= NCLS; ++k) { ustart[k] = tab->unit_start[oi][k]; bstart[k] = tab->bucket_start[oi][k]; }
+    const int total = ustart[NCLS];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        int k = 0, u0 = ustart[0], lo = bstart[0], hi = bstart[1];
+#pragma unroll
+        for (int q = 1; q < NCLS; ++q)
+            if (u >= ustart[q]) { k = q; u0 = ustart[q]; lo = bstart[q]; hi = bstart[q + 1]; }   // wave-uniform selects
+        const int lpt_log2 = 6 - k;
+        const int idx = lo + (((u - u0) * 64 + lane) >> lpt_log2);
+        const bool traj_ok = idx < hi;
+        const int64_t bb = perm[traj_ok ? idx : hi - 1];
+        const int64_t seg0 = a.seg_off[bb];
+        const int S = (int)(a.seg_off[bb + 1] - seg0);
+        chunked::chunked_body<O, IO, STATUS, true>(a, lds, xch, lane, lpt_log2, traj_ok, bb, seg0, S, coef_off[bb]);
+        __syncthreads();   // the LDS images are reused by the next unit
+    }
+}
+
+template <int O> hipError_t launch_order(const GenericArgs &a, bool f32, const int32_t *perm, const int64_t *coef_off, const MixedTable *tab,
+                                         int waves, hipStream_t st) {
+    const dim3 grid((unsigned)waves), block(64);
+    if (a.status) {
+        if (f32) hipLaunchKernelGGL((minsnap_chunked_mixed_kernel<O, float, true>), grid, block, 0, st, a, perm, coef_off, tab);
+        else hipLaunchKernelGGL((minsnap_chunked_mixed_kernel<O, double, true>), grid, block, 0, st, a, perm, coef_off, tab);
+    } else {
+        if (f32) hipLaunchKernelGGL((minsnap_chunked_mixed_kernel<O, float, false>), grid, block, 0, st, a, perm, coef_off, tab);
+        else hipLaunchKernelGGL((minsnap_chunked_mixed_kernel<O, double, false>), grid, block, 0, st, a, perm, coef_off, tab);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mixed
+
+size_t mixed_workspace_bytes(int64_t B) {
+    const int64_t nblk = (B + mixed::BT * mixed::ITEMS - 1) / (mixed::BT * mixed::ITEMS);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    return up(sizeof(MixedTable)) + up((size_t)(nblk + 1) * 8) + up((size_t)nblk * 28 * 4) + up((size_t)(B + 1) * 8) + up((size_t)B * 4);
+}
+
+// Forked streams of one device for the per-order launches (created once per device and thread, never destroyed: the
+// library has no teardown hook; four streams and eight events per device).
+namespace {
+struct Fork {
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t begin = nullptr, done[3] = {nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+Fork *fork_for_device() {
+    static thread_local Fork forks[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Fork &f = forks[dev];
+    if (!f.ok) {
+        for (int i = 0; i < 3; ++i) {
+            if (hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&f.done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&f.begin, hipEventDisableTiming) != hipSuccess) return nullptr;
+        f.ok = true;
+    }
+    return &f;
+}
+}  // namespace
+
+hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, void *workspace, int64_t *coef_off_out, hipStream_t st) {
+    using namespace mixed;
+    if (a.B == 0) return hipSuccess;
+    const int64_t B = a.B;
+    const int64_t nblk = (B + BT * ITEMS - 1) / (BT * ITEMS);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char *w = (char *)workspace;
+    MixedTable *tab = (MixedTable *)w;                 w += up(sizeof(MixedTable));
+    int64_t *block_sum = (int64_t *)w;                 w += up((size_t)(nblk + 1) * 8);
+    int32_t *hist_blk = (int32_t *)w;                  w += up((size_t)nblk * 28 * 4);
+    int64_t *coef_ws = (int64_t *)w;                   w += up((size_t)(B + 1) * 8);
+    int32_t *perm = (int32_t *)w;
+    int64_t *coef_off = coef_off_out ? coef_off_out : coef_ws;
+    hipError_t e;
+    // no memsets: the three kernels write every word they or the solve read (status included)
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, hist_blk, block_sum);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(BT), 0, st, tab, hist_blk, block_sum, nblk, coef_off, B);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, tab, hist_blk, block_sum, coef_off, perm, a.status);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // persistent grids: what one order can keep resident (CUs x SIMDs x waves per SIMD), capped by the work there can be
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    // a unit holds at least one trajectory, so B units bound every order's list
+    auto waves_for = [&](int per_simd) { const int64_t cap = (int64_t)cus * 4 * per_simd; return (int)(B < cap ? B : cap); };
+    Fork *f = fork_for_device();
+    if (!f) {   // no side streams: the four orders one after the other on the caller's stream
+        if ((e = launch_order<5>(a, f32, perm, coef_off, tab, waves_for(1), st)) != hipSuccess) return e;
+        if ((e = launch_order<4>(a, f32, perm, coef_off, tab, waves_for(2), st)) != hipSuccess) return e;
+        if ((e = launch_order<3>(a, f32, perm, coef_off, tab, waves_for(2), st)) != hipSuccess) return e;
+        return launch_order<2>(a, f32, perm, coef_off, tab, waves_for(2), st);
+    }
+    if ((e = hipEventRecord(f->begin, st)) != hipSuccess) return e;
+    for (int i = 0; i < 3; ++i)
+        if ((e = hipStreamWaitEvent(f->s[i], f->begin, 0)) != hipSuccess) return e;
+    // the most expensive order first; order 2 shares the caller's stream with order 5
+    if ((e = launch_order<5>(a, f32, perm, coef_off, tab, waves_for(1), st)) != hipSuccess) return e;
+    if ((e = launch_order<4>(a, f32, perm, coef_off, tab, waves_for(2), f->s[0])) != hipSuccess) return e;
+    if ((e = launch_order<3>(a, f32, perm, coef_off, tab, waves_for(2), f->s[1])) != hipSuccess) return e;
+    if ((e = launch_order<2>(a, f32, perm, coef_off, tab, waves_for(2), f->s[2])) != hipSuccess) return e;
+    for (int i = 0; i < 3; ++i) {
+        if ((e = hipEventRecord(f->done[i], f->s[i])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, f->done[i], 0)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace csp

@@ -81,6 +81,8 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
                                   the path-penalty kernels test the highest-power and constant coefficient of
                                   every record, which every input and unknown of the segment enters         */
 #define CSP_TRAJ_NOT_SPD 2     /* a pivot of the free-derivative Hessian R_PP was <= 0              */
+#define CSP_TRAJ_SKIPPED 4     /* csp_minsnap_solve_mixed only: the trajectory was NOT solved (its order is outside 2..5
+                                  or its segment count outside 1..256); its coefficient block is left untouched (zero-filled with CSP_MEM_HOST) */
 
 typedef struct csp_minsnap_desc {
     uint32_t abi_version;       /* CSP_MINSNAP_ABI_VERSION                                       */
@@ -129,6 +131,28 @@ size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
  * the results are bit-identical to csp_minsnap_solve_batch on one device. */
 int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                                     const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu);
+
+/* Mixed-ORDER ragged batches in ONE call (BASELINE config 5: per-trajectory segment count AND derivative order).  The
+ * reference solves one flight per call with one `order` (TrajectoryGeneratorTool::SolveQPClosedForm,
+ * math_util/minimum_snap.hpp:45-53); a planner that batches flights of different smoothness classes would otherwise have to
+ * sort them by order itself.  Here the bucketing by (order, length class) runs on the device and the solve reads the inputs
+ * and writes the coefficients IN THE CALLER'S ORDER -- nothing is gathered or un-permuted:
+ *   desc        : dtype, batch, seg_offsets ([B+1], ragged layout as above), max_segments (<= 256), bc_per_trajectory,
+ *                 vel_zero_weight(_per_traj), mem_space, device_id as for csp_minsnap_solve_batch; desc->order and
+ *                 num_segments are ignored; path_weight must be 0 and CSP_FLAG_F32_ARITH is not offered (CSP_ERR_UNSUPPORTED)
+ *   orders      : [B] int32, derivative order of every trajectory, 2..5 (same memory space as the data)
+ *   coeffs      : trajectory b's block [S_b][3][2*order_b] starts at element coeff_offsets[b] = sum_{k<b} 6*order_k*S_k
+ *                 (tightly concatenated in caller order; the caller sizes it, e.g. from its own host copy of the shapes)
+ *   coeff_offsets_out : optional [B+1] int64, the offsets above (computed on the device)
+ *   status      : optional [B] int32 CSP_TRAJ_* bits; trajectories outside the served range get CSP_TRAJ_SKIPPED
+ *   workspace   : >= csp_minsnap_mixed_workspace_bytes(desc) bytes of device memory (CSP_MEM_DEVICE); NULL/0 with CSP_MEM_HOST
+ * Per trajectory the arithmetic is csp_minsnap_solve_batch's workspace-free kernel for that order and length class.
+ * CSP_MEM_DEVICE: asynchronous on `hip_stream` (the per-order launches run on internal streams forked from and joined
+ * back into it).  CSP_MEM_HOST: staged through the cached arena, synchronous. */
+int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders, const void *waypoints, const void *times,
+                            const void *bc, void *coeffs, int64_t *coeff_offsets_out, int32_t *status,
+                            void *workspace, size_t workspace_bytes, void *hip_stream);
+size_t csp_minsnap_mixed_workspace_bytes(const csp_minsnap_desc *desc);
 
 /* Replaces the time-allocation step of TrajectoryGeneratorTool::GenerateTrajectoryMatrix
  * (minimum_snap.cpp:59-72): T_i = max(|p_{i+1}-p_i| / V_avg, min_time_s), or min_time_s when

@@ -362,10 +362,12 @@ def test_axis_per_lane_mapping_of_small_batches(csp, oracle_mod, S):
 
 def test_c5_full_size_mixed_batch(csp, oracle_mod):
     """BASELINE C5 at the size bench.py times: B = 65536 mixed trajectories (S ~ U{4..64}, order ~ U{3,4,5}), fp32 storage /
-    fp64 arithmetic, bucketed by order and length class (cs-pathplan_amd/mixed.py::MixedBatch, nine ragged launches).
-    Size-independent properties on every trajectory of every bucket (interpolation of the waypoints at both segment ends,
+    fp64 arithmetic, through csp_minsnap_solve_mixed (round 3: ONE C-ABI call, device-side bucketing by (order, length class),
+    one persistent launch per order, coefficients in the CALLER'S order; cs-pathplan_amd/mixed.py::MixedBatch is a thin
+    caller).  Size-independent properties on every trajectory (interpolation of the waypoints at both segment ends,
     continuity of velocity and acceleration at interior waypoints, zero boundary velocity / acceleration -- all to fp32
-    resolution) and 192 trajectories spread over the batch against the 80-bit oracle on the fp32-rounded inputs."""
+    resolution), the device-computed coefficient offsets against the host's, status clean, and 192 trajectories spread over
+    the batch against the 80-bit oracle on the fp32-rounded inputs."""
     import importlib.util, os
     import torch
     spec = importlib.util.spec_from_file_location("csp_mixed", os.path.join(os.path.dirname(csp.__file__), "mixed.py"))
@@ -373,22 +375,38 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
     spec.loader.exec_module(mixed)
     B = 65536
     trajs = synth.make_ragged(B)
-    mb = mixed.MixedBatch(csp, trajs, torch.device("cuda", 0), dtype=torch.float32)
-    assert mb.launches == 9 and all(k.endswith("_ragged") and "f32io_f64" in k for k in mb.kernels), mb.kernels
-    mb.run()
+    dev = torch.device("cuda", 0)
+    orders, wp_h, tm_h, off_h = mixed.pack(trajs, np.float32)
+    d_or, d_wp, d_tm, d_off = (torch.from_numpy(x).to(dev) for x in (orders, wp_h, tm_h, off_h))
+    prep = csp.PreparedMixed(d_or, d_wp, d_tm, d_off, want_status=True)
+    prep.out.fill_(float("nan"))      # every element must be written
+    prep.run()
+    prep.run()                        # a second call on the same workspace (counters and cursors are reset by the call)
     torch.cuda.synchronize()
-    for ps in mb.buckets:
-        o, m = ps.desc.order, 2 * ps.desc.order
-        co = ps.out.double()                                        # [sum S, 3, m]
-        assert bool(torch.isfinite(co).all())
-        off = ps.off
-        lens = off[1:] - off[:-1]
-        seg_traj = torch.repeat_interleave(torch.arange(lens.numel(), device=co.device), lens)   # trajectory of each segment
-        wp = ps.wp.double()                                         # [sum S + B, 3]
-        seg_idx = torch.arange(co.shape[0], device=co.device)
-        p_start = wp[seg_idx + seg_traj]                            # waypoint at each segment's start
-        p_end = wp[seg_idx + seg_traj + 1]
-        T = ps.tm.double()[:, None].expand(-1, 3)
+    assert int(prep.status.abs().max()) == 0
+    host_off = np.concatenate([[0], np.cumsum(np.diff(off_h) * 6 * orders.astype(np.int64))])
+    assert np.array_equal(prep.coeff_offsets.cpu().numpy(), host_off)
+    out = prep.out
+    assert bool(torch.isfinite(out).all())
+    lens = d_off[1:] - d_off[:-1]
+    seg_traj = torch.repeat_interleave(torch.arange(B, device=dev), lens)                 # trajectory of each segment
+    seg_idx = torch.arange(int(d_off[-1]), device=dev)
+    seg_local = seg_idx - d_off[seg_traj]
+    seg_order = d_or.long()[seg_traj]
+    seg_coef = prep.coeff_offsets[seg_traj] + seg_local * 6 * seg_order                   # element offset of each record
+    first_all = torch.zeros_like(seg_idx, dtype=torch.bool)
+    first_all[d_off[:-1]] = True
+    last_all = torch.zeros_like(first_all)
+    last_all[d_off[1:] - 1] = True
+    for o in (3, 4, 5):
+        m = 2 * o
+        sel = seg_order == o
+        g = seg_idx[sel]
+        co = out[(seg_coef[sel][:, None] + torch.arange(3 * m, device=dev)[None, :])].reshape(-1, 3, m).double()
+        wp = d_wp.double()
+        p_start, p_end = wp[g + seg_traj[sel]], wp[g + seg_traj[sel] + 1]
+        T = d_tm.double()[g][:, None].expand(-1, 3)
+        first, last = first_all[sel], last_all[sel]
         # fp32 coefficients: a value of the polynomial is only as good as 6e-8 x the sum of the magnitudes of its terms
         # (they cancel), so every check is scaled by that sum
         def mag_at(t, j):
@@ -396,10 +414,6 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
         eps = 4e-7
         assert float((co[..., m - 1] - p_start).abs().max()) == 0.0                      # constant term = waypoint, bit for bit (fp32)
         assert bool(((_deriv_at(torch, co, T, 0, o) - p_end).abs() <= eps * mag_at(T, 0)).all())
-        first = torch.zeros(co.shape[0], dtype=torch.bool, device=co.device)
-        first[off[:-1]] = True
-        last = torch.zeros_like(first)
-        last[off[1:] - 1] = True
         zero = torch.zeros_like(T)
         for j in (1, 2):
             end, start = _deriv_at(torch, co, T, j, o), _deriv_at(torch, co, zero, j, o)
@@ -412,14 +426,24 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
     idx = np.linspace(0, B - 1, 192).astype(np.int64)
     z = np.zeros((2, 3))
     worst = {3: 0.0, 4: 0.0, 5: 0.0}
+    out_h = out.cpu().numpy()
     for i in idx:
         o, w, t = trajs[i]
         w32, t32 = w.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
         ref, _ = oracle_mod.solve(o, w32, z, z, t32, long_double=True)
-        got = mb.coeffs(int(i)).double().cpu().numpy().reshape(ref.shape)
+        got = out_h[host_off[i]:host_off[i + 1]].astype(np.float64).reshape(ref.shape)
         worst[o] = max(worst[o], float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
     print("C5 full size, 192 of 65536 trajectories vs the 80-bit oracle (norm-wise, fp32 storage):", worst)
     assert all(v < 1e-6 for v in worst.values()), worst
+    # MixedBatch (bench.py's object) is the same call
+    mb = mixed.MixedBatch(csp, trajs[:5000], dev, dtype=torch.float32)
+    mb.run()
+    torch.cuda.synchronize()
+    small = csp.PreparedMixed(d_or[:5000], d_wp[:int(off_h[5000]) + 5000], d_tm[:int(off_h[5000])], d_off[:5001])
+    small.run()
+    torch.cuda.synchronize()
+    assert torch.equal(mb.prep.out, small.out)
+    assert torch.equal(mb.coeffs(4999), small.out[int(host_off[4999]):int(host_off[5000])].reshape(len(trajs[4999][2]), 3, 2 * trajs[4999][0]))
 
 
 @pytest.mark.parametrize("S", [8, 11, 13, 14, 15, 16])

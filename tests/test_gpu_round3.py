@@ -137,3 +137,53 @@ def test_path_kernel_whole_line_stores_and_the_skip_mask(csp, oracle_mod, order,
         assert abs(md[b] - info["max_dev"]) < 1e-7 * max(1.0, info["max_dev"])
         synth.parity_gate(co[b], info["coeff"], 1e-6, ("path ring stores, loop, vs oracle", order, S, b))
     assert n_loop > 0 and (it[:64] == 0).all()
+
+
+def test_mixed_entry_edge_cases(csp, oracle_mod):
+    """csp_minsnap_solve_mixed: orders 2..5 together, fp64 storage, every length class (1 .. 256 segments), per-trajectory
+    boundary conditions and weights (host-memory form), unsupported trajectories flagged CSP_TRAJ_SKIPPED and left alone, an
+    empty batch, and the validation errors."""
+    import torch
+    rng = np.random.default_rng(77)
+    lens = np.array([1, 2, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 256, 3, 7, 40, 100, 200] * 3)
+    B = len(lens)
+    orders = rng.integers(2, 6, size=B).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    wps, tms = [], []
+    for n in lens:
+        p0 = rng.uniform(-10, 10, size=(1, 3))
+        wps.append(np.concatenate([p0, p0 + np.cumsum(rng.normal(size=(int(n), 3)), axis=0)]))
+        tms.append(rng.uniform(0.5, 2.0, size=int(n)))
+    wp, tm = np.concatenate(wps), np.concatenate(tms)
+    bc = rng.normal(size=(B, 4, 3))
+    vw = rng.uniform(0, 0.2, size=B)
+    r = csp.solve_mixed(orders, wp, tm, off, bc=bc, vel_zero_weight_per_traj=vw, want_status=True)
+    assert not r.status.any()
+    for i in range(B):
+        o, n = int(orders[i]), int(lens[i])
+        got = r.coeffs[r.coeff_offsets[i]:r.coeff_offsets[i + 1]].reshape(n, 3, 2 * o)
+        one = csp.solve_batch(wps[i], tms[i], bc[i][None], order=o, seg_offsets=np.array([0, n]), vel_zero_weight=float(vw[i]),
+                              max_segments=n, force_generic=n <= 0)
+        if n <= 64 and not (o == 5 and n > 32):
+            ref, _ = oracle_mod.solve(o, wps[i], bc[i, [0, 1]], bc[i, [2, 3]], tms[i], 0.0, float(vw[i]), long_double=o == 5)
+            synth.parity_gate(got, ref, 1e-6 if o == 5 else 5e-8, ("mixed entry vs oracle", i, o, n))
+        synth.parity_gate(got, one.coeffs, 5e-5 if o == 5 else 1e-8, ("mixed entry vs single ragged call", i, o, n))
+    # device form, unsupported trajectories among good ones
+    bad_orders = orders.copy()
+    bad_orders[3], bad_orders[10] = 1, 6
+    d = [torch.from_numpy(x).cuda() for x in (bad_orders, wp, tm, off)]
+    p = csp.PreparedMixed(d[0], d[1], d[2], d[3], bc=torch.from_numpy(bc).cuda(), want_status=True)
+    p.out.fill_(-7.0)
+    p.run()
+    torch.cuda.synchronize()
+    st = p.status.cpu().numpy()
+    assert st[3] == csp.TRAJ_SKIPPED and st[10] == csp.TRAJ_SKIPPED and not np.delete(st, [3, 10]).any()
+    cof = p.coeff_offsets.cpu().numpy()
+    o_h = p.out.cpu().numpy()
+    assert (o_h[cof[3]:cof[4]] == -7.0).all() and (o_h[cof[10]:cof[11]] == -7.0).all()
+    assert not (o_h[cof[4]:cof[10]] == -7.0).any()
+    # empty batch, bad arguments
+    e = csp.solve_mixed(np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros(0), np.zeros(1, np.int64))
+    assert e.coeff_offsets.shape == (1,)
+    with pytest.raises(csp.CspError):
+        csp.solve_mixed(orders, wp, tm, off, max_segments=300)
