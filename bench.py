@@ -215,6 +215,34 @@ def end_to_end(args, csp, dev, dist, rank, world, share):
     return rec
 
 
+def end_to_end_cabi(args, csp, dev):
+    """The same root-scatter / solve / root-gather pipeline INSIDE the C-ABI (csp_minsnap_solve_batch_sharded, CSP_MEM_DEVICE:
+    single-process RCCL communicators, grouped send/recv, chunked overlap), from this one process over args.e2e_cabi devices."""
+    n = args.e2e_cabi
+    if n > csp.device_count():
+        return {"error": "%d devices asked for, %d visible" % (n, csp.device_count())}
+    S, o = args.segments, args.order
+    total = args.batch * n if args.scaling == "weak" else args.batch
+    wp, tm = synth.make_batch(total, S, config_id=3)
+    d_wp, d_tm = torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev)
+    out = torch.empty((total, S, 3, 2 * o), dtype=torch.float64, device=dev)
+    for _ in range(max(1, args.warmup)):
+        csp.solve_batch(d_wp, d_tm, order=o, out=out, ngpu=n)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        csp.solve_batch(d_wp, d_tm, order=o, out=out, ngpu=n)     # synchronous
+    elapsed = time.perf_counter() - t0
+    chk = min(total, 4096)
+    ref = csp.solve_batch(d_wp[:chk].contiguous(), d_tm[:chk].contiguous(), order=o).coeffs
+    tail = csp.solve_batch(d_wp[total - chk:].contiguous(), d_tm[total - chk:].contiguous(), order=o).coeffs
+    torch.cuda.synchronize(dev)
+    return {"mode": "csp_minsnap_solve_batch_sharded, CSP_MEM_DEVICE, %d device(s), one process" % n, "total_batch": total,
+            "solves_per_s": total * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+            "bit_equal_to_one_device": bool(torch.equal(out[:chk], ref) and torch.equal(out[total - chk:], tail)),
+            "verified_on_more_than_one_gpu": n > 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +266,9 @@ def main():
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time the root-scatter / solve / root-gather pipeline (SURVEY.md 8e) and report it as `end_to_end`")
     ap.add_argument("--e2e-chunks", type=int, default=4)
+    ap.add_argument("--e2e-cabi", type=int, default=0, metavar="NGPU",
+                    help="single process only (no torchrun): also time csp_minsnap_solve_batch_sharded with a device-resident batch over "
+                         "NGPU devices (RCCL scatter / solve / gather inside the C-ABI) and report it as `end_to_end_cabi`")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the CSP_MEM_HOST boundary (PCIe-inclusive; reported as a side note, never `value`)")
     args = ap.parse_args()
@@ -357,6 +388,8 @@ def main():
         }
         if e2e is not None:
             res["end_to_end"] = e2e
+        if args.e2e_cabi and world == 1:
+            res["end_to_end_cabi"] = end_to_end_cabi(args, csp, dev)
         if args.host_path and world == 1:
             # PCIe-inclusive rate from PAGEABLE caller memory; the result array is allocated and touched once, outside
             # the timed region (numpy's allocation + first-touch faults of a 201 MB array cost more than the transfer)

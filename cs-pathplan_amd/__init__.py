@@ -253,6 +253,14 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
         if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
             workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        if ngpu is not None:
+            # the batch is resident on THIS (root) device: scatter / solve / gather over RCCL from one process, synchronous
+            # (include/csp_minsnap.h: csp_minsnap_solve_batch_sharded with CSP_MEM_DEVICE)
+            rc = _lib.csp_minsnap_solve_batch_sharded(
+                ctypes.byref(desc), waypoints.data_ptr(), times.data_ptr(), bc.data_ptr(), out.data_ptr(),
+                md.data_ptr() if md is not None else None, stt.data_ptr() if stt is not None else None, int(ngpu))
+            _check(rc)
+            return Result(out, md, stt, kernel_name(desc))
         rc = _lib.csp_minsnap_solve_batch(
             ctypes.byref(desc), waypoints.data_ptr(), times.data_ptr(), bc.data_ptr(), out.data_ptr(),
             md.data_ptr() if md is not None else None, stt.data_ptr() if stt is not None else None,

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libcsp_minsnap.so")
 SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_chunked.hip", "minsnap_mixed.hip", "minsnap_span.hip", "minsnap_fixed.hip", "minsnap_fixed_o2.hip", "minsnap_fixed_o3.hip",
            "minsnap_fixed_o4a.hip", "minsnap_fixed_o4b.hip", "minsnap_fixed_o5.hip",
            "minsnap_fixedpath_o2.hip", "minsnap_fixedpath_o3.hip", "minsnap_fixedpath_o4a.hip", "minsnap_fixedpath_o4b.hip", "minsnap_timealloc.hip", "minsnap_plan.hip", "geo.hip", "alt.hip", "bezier.hip"]
-HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_hoststage.h", "minsnap_timealloc.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h", "minsnap_chunked_impl.h", "minsnap_mixed.h",
+HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_hoststage.h", "minsnap_timealloc.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h", "minsnap_chunked_impl.h", "minsnap_mixed.h", "minsnap_shard_schedule.h",
            os.path.join("..", "..", "include", "csp_minsnap.h"), os.path.join("..", "..", "include", "csp_geo.h"), os.path.join("..", "..", "include", "csp_alt.h"), os.path.join("..", "..", "include", "csp_bezier.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
@@ -60,7 +60,7 @@ def build(force=False, verbose=False, stamps=False):
     if stamps:
         out = os.path.join(HERE, "libcsp_minsnap_stamps.so")
         objs = _compile_all(["-DCSP_STAMPS"], "_stamps", verbose)
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
         return out
     if force and os.path.isdir(OBJDIR):
         for f in os.listdir(OBJDIR):
@@ -69,7 +69,8 @@ def build(force=False, verbose=False, stamps=False):
     if not (force or _stale()):
         return LIB
     objs = _compile_all([], "", verbose)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    # RCCL: csp_minsnap_solve_batch_sharded with device memory scatters / gathers over xGMI (minsnap_capi.hip, RcclTransport)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 
@@ -99,7 +100,7 @@ def build_tsan_check(out=None):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950"] + common +
                           ["-x", "c++", os.path.join(HERE, "host", "tsan_driver.cpp"), "-x", "none", tsan_obj] + others +
                           ["-I", os.path.join(HERE, "..", "include"), "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+                           "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
     return out
 
 

@@ -6,12 +6,15 @@
 #include "minsnap_launch.h"
 #include "minsnap_hoststage.h"
 #include "minsnap_timealloc.h"
+#include "minsnap_shard_schedule.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -183,6 +186,272 @@ int dispatch(const csp_minsnap_desc *d, const Shape &s, const void *wp, const vo
                                      : csp::launch_generic(a, s.f32, (d->flags & CSP_FLAG_F32_ARITH) != 0, st);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CSP_OK;
+}
+
+
+// ---- csp_minsnap_solve_batch_sharded for a batch RESIDENT ON A ROOT DEVICE: scatter / solve / gather over RCCL -------------
+// (the schedule itself is minsnap_shard_schedule.h; this is its transport).  One process, one thread: single-process
+// communicators (ncclCommInitAll, cached per device list), per device a compute stream and a communication stream, an arena
+// on every peer for its shard's inputs and outputs.  UNVERIFIED ON MORE THAN ONE GPU: the development boxes have one; what
+// runs there is the ngpu = 1 degenerate path (no communicator) and, on the CPU, the schedule over a recording transport.
+struct ShardNode {
+    std::vector<int> devs;              // HIP ordinals, devs[root] owns the caller's buffers
+    std::vector<ncclComm_t> comms;      // empty for one device
+    std::vector<hipStream_t> compute, comm;
+};
+
+int nccl_fail(ncclResult_t r, const char *what) {
+    g_last_hip_error = std::string(what) + ": " + ncclGetErrorString(r);
+    return CSP_ERR_HIP;
+}
+#define CSP_NCCL(call)                                       \
+    do {                                                     \
+        ncclResult_t r_ = (call);                            \
+        if (r_ != ncclSuccess) return nccl_fail(r_, #call);  \
+    } while (0)
+
+// cached for the life of the process (communicator set-up costs hundreds of milliseconds)
+int shard_node(const std::vector<int> &devs, ShardNode **out) {
+    static std::mutex m;
+    static std::map<std::vector<int>, ShardNode *> cache;
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find(devs);
+    if (it != cache.end()) { *out = it->second; return CSP_OK; }
+    std::unique_ptr<ShardNode> n(new ShardNode());
+    n->devs = devs;
+    n->compute.resize(devs.size());
+    n->comm.resize(devs.size());
+    for (size_t i = 0; i < devs.size(); ++i) {
+        CSP_HIP(hipSetDevice(devs[i]));
+        CSP_HIP(hipStreamCreateWithFlags(&n->compute[i], hipStreamNonBlocking));
+        CSP_HIP(hipStreamCreateWithFlags(&n->comm[i], hipStreamNonBlocking));
+    }
+    if (devs.size() > 1) {
+        n->comms.resize(devs.size());
+        CSP_NCCL(ncclCommInitAll(n->comms.data(), (int)devs.size(), devs.data()));
+    }
+    *out = n.get();
+    cache[devs] = n.release();
+    return CSP_OK;
+}
+
+struct RcclTransport {
+    const csp_minsnap_desc *desc;
+    Shape s;
+    ShardNode *node;
+    int root, nchunks;
+    // caller's buffers on the root device
+    const char *wp, *tm, *bc;
+    char *co;
+    double *max_dev;
+    int32_t *status;
+    // per device: arena + carved offsets of its shard (peers only), events
+    struct Dev {
+        csp::Arena *arena = nullptr;
+        int64_t lo = 0, hi = 0;
+        size_t o_wp = 0, o_tm = 0, o_bc = 0, o_vw = 0, o_co = 0, o_md = 0, o_st = 0, o_ws = 0, ws_bytes = 0;
+        std::vector<hipEvent_t> in_ready, solved;
+    };
+    std::vector<Dev> dev;
+    size_t m() const { return 2 * (size_t)s.order; }
+    size_t wp_bytes(int64_t n) const { return (size_t)n * (size_t)(s.S + 1) * 3 * s.elt; }
+    size_t tm_bytes(int64_t n) const { return (size_t)n * (size_t)s.S * s.elt; }
+    size_t co_bytes(int64_t n) const { return (size_t)n * (size_t)s.S * 3 * m() * s.elt; }
+
+    int setup() {
+        const int nd = (int)node->devs.size();
+        dev.resize((size_t)nd);
+        for (int g = 0; g < nd; ++g) {
+            Dev &d = dev[(size_t)g];
+            csp::shard::shard_range(s.B, nd, g, d.lo, d.hi);
+            const int64_t n = d.hi - d.lo;
+            CSP_HIP(hipSetDevice(node->devs[(size_t)g]));
+            d.in_ready.resize((size_t)nchunks);
+            d.solved.resize((size_t)nchunks);
+            for (int c = 0; c < nchunks; ++c) {
+                CSP_HIP(hipEventCreateWithFlags(&d.in_ready[(size_t)c], hipEventDisableTiming));
+                CSP_HIP(hipEventCreateWithFlags(&d.solved[(size_t)c], hipEventDisableTiming));
+            }
+            // the solve of a piece may need the generic kernel's workspace: sized for the largest piece
+            csp_minsnap_desc pd = *desc;
+            pd.batch = (n + nchunks - 1) / nchunks;
+            Shape ps;
+            if (validate(&pd, ps) != CSP_OK) return CSP_ERR_INVALID_ARG;
+            d.ws_bytes = ws_bytes(&pd, ps, nullptr);
+            if (g == root && d.ws_bytes == 0) continue;
+            d.arena = csp::arena_acquire(node->devs[(size_t)g]);
+            size_t top = 0;
+            auto carve = [&](size_t bytes) { const size_t o = top; top = align_up(top + bytes, 256); return o; };
+            if (g != root) {
+                d.o_wp = carve(wp_bytes(n));
+                d.o_tm = carve(tm_bytes(n));
+                d.o_bc = carve(desc->bc_per_trajectory ? (size_t)n * 12 * s.elt : 12 * s.elt);
+                d.o_vw = carve(desc->vel_zero_weight_per_traj ? (size_t)n * 8 : 0);
+                d.o_co = carve(co_bytes(n));
+                d.o_md = carve(max_dev ? (size_t)n * 8 : 0);
+                d.o_st = carve(status ? (size_t)n * 4 : 0);
+            }
+            d.o_ws = carve(d.ws_bytes);
+            CSP_HIP(d.arena->reserve(top));
+        }
+        return CSP_OK;
+    }
+    void teardown() {
+        for (size_t g = 0; g < dev.size(); ++g) {
+            if (hipSetDevice(node->devs[g]) != hipSuccess) continue;
+            for (hipEvent_t e : dev[g].in_ready) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : dev[g].solved) if (e) (void)hipEventDestroy(e);
+            if (dev[g].arena) csp::arena_release(dev[g].arena);
+        }
+        (void)hipSetDevice(node->devs[(size_t)root]);
+    }
+
+    // ---- the Transport concept of minsnap_shard_schedule.h ----
+    int scatter_begin(int) { if (!node->comms.empty()) CSP_NCCL(ncclGroupStart()); return 0; }
+    int scatter_piece(const csp::shard::Piece &p) {
+        Dev &d = dev[(size_t)p.dev];
+        const int64_t n = p.hi - p.lo, off = p.lo - d.lo;
+        hipStream_t rs = node->comm[(size_t)root], ps = node->comm[(size_t)p.dev];
+        ncclComm_t rc = node->comms[(size_t)root], pc = node->comms[(size_t)p.dev];
+        CSP_NCCL(ncclSend(wp + wp_bytes(p.lo), wp_bytes(n), ncclChar, p.dev, rc, rs));
+        CSP_NCCL(ncclRecv(d.arena->dev + d.o_wp + wp_bytes(off), wp_bytes(n), ncclChar, root, pc, ps));
+        CSP_NCCL(ncclSend(tm + tm_bytes(p.lo), tm_bytes(n), ncclChar, p.dev, rc, rs));
+        CSP_NCCL(ncclRecv(d.arena->dev + d.o_tm + tm_bytes(off), tm_bytes(n), ncclChar, root, pc, ps));
+        if (desc->bc_per_trajectory) {
+            CSP_NCCL(ncclSend(bc + (size_t)p.lo * 12 * s.elt, (size_t)n * 12 * s.elt, ncclChar, p.dev, rc, rs));
+            CSP_NCCL(ncclRecv(d.arena->dev + d.o_bc + (size_t)off * 12 * s.elt, (size_t)n * 12 * s.elt, ncclChar, root, pc, ps));
+        } else if (p.chunk == 0) {
+            CSP_NCCL(ncclSend(bc, 12 * s.elt, ncclChar, p.dev, rc, rs));
+            CSP_NCCL(ncclRecv(d.arena->dev + d.o_bc, 12 * s.elt, ncclChar, root, pc, ps));
+        }
+        if (desc->vel_zero_weight_per_traj) {
+            CSP_NCCL(ncclSend(desc->vel_zero_weight_per_traj + p.lo, (size_t)n * 8, ncclChar, p.dev, rc, rs));
+            CSP_NCCL(ncclRecv(d.arena->dev + d.o_vw + (size_t)off * 8, (size_t)n * 8, ncclChar, root, pc, ps));
+        }
+        return 0;
+    }
+    int scatter_end(int c) {
+        if (node->comms.empty()) return 0;
+        CSP_NCCL(ncclGroupEnd());
+        for (size_t g = 0; g < dev.size(); ++g) {
+            if ((int)g == root) continue;
+            CSP_HIP(hipSetDevice(node->devs[g]));
+            CSP_HIP(hipEventRecord(dev[g].in_ready[(size_t)c], node->comm[g]));
+        }
+        return 0;
+    }
+    int solve(const csp::shard::Piece &p) {
+        Dev &d = dev[(size_t)p.dev];
+        const int64_t n = p.hi - p.lo, off = p.lo - d.lo;
+        CSP_HIP(hipSetDevice(node->devs[(size_t)p.dev]));
+        hipStream_t st = node->compute[(size_t)p.dev];
+        csp_minsnap_desc pd = *desc;
+        pd.batch = n;
+        pd.mem_space = CSP_MEM_DEVICE;
+        pd.device_id = node->devs[(size_t)p.dev];
+        Shape ps;
+        int rc = validate(&pd, ps);
+        if (rc != CSP_OK) return rc;
+        void *ws = d.ws_bytes ? (void *)(d.arena->dev + d.o_ws) : nullptr;
+        if (p.dev == root) {
+            rc = dispatch(&pd, ps, wp + wp_bytes(p.lo), tm + tm_bytes(p.lo), bc + (desc->bc_per_trajectory ? (size_t)p.lo * 12 * s.elt : 0),
+                          co + co_bytes(p.lo), max_dev ? max_dev + p.lo : nullptr, status ? status + p.lo : nullptr, nullptr,
+                          desc->vel_zero_weight_per_traj ? desc->vel_zero_weight_per_traj + p.lo : nullptr, ws, d.ws_bytes, st);
+        } else {
+            CSP_HIP(hipStreamWaitEvent(st, d.in_ready[(size_t)p.chunk], 0));
+            char *a = d.arena->dev;
+            rc = dispatch(&pd, ps, a + d.o_wp + wp_bytes(off), a + d.o_tm + tm_bytes(off),
+                          a + d.o_bc + (desc->bc_per_trajectory ? (size_t)off * 12 * s.elt : 0), a + d.o_co + co_bytes(off),
+                          max_dev ? (double *)(a + d.o_md) + off : nullptr, status ? (int32_t *)(a + d.o_st) + off : nullptr, nullptr,
+                          desc->vel_zero_weight_per_traj ? (const double *)(a + d.o_vw) + off : nullptr, ws, d.ws_bytes, st);
+        }
+        if (rc != CSP_OK) return rc;
+        CSP_HIP(hipEventRecord(d.solved[(size_t)p.chunk], st));
+        return 0;
+    }
+    int gather_begin(int c) {
+        if (node->comms.empty()) return 0;
+        // a peer's communication stream sends piece c after ITS solve of c only
+        for (size_t g = 0; g < dev.size(); ++g) {
+            if ((int)g == root) continue;
+            const csp::shard::Piece p = csp::shard::piece_of(s.B, (int)dev.size(), nchunks, (int)g, c);
+            if (p.hi <= p.lo) continue;
+            CSP_HIP(hipSetDevice(node->devs[g]));
+            CSP_HIP(hipStreamWaitEvent(node->comm[g], dev[g].solved[(size_t)c], 0));
+        }
+        CSP_NCCL(ncclGroupStart());
+        return 0;
+    }
+    int gather_piece(const csp::shard::Piece &p) {
+        Dev &d = dev[(size_t)p.dev];
+        const int64_t n = p.hi - p.lo, off = p.lo - d.lo;
+        hipStream_t rs = node->comm[(size_t)root], ps = node->comm[(size_t)p.dev];
+        ncclComm_t rc = node->comms[(size_t)root], pc = node->comms[(size_t)p.dev];
+        char *a = d.arena->dev;
+        CSP_NCCL(ncclSend(a + d.o_co + co_bytes(off), co_bytes(n), ncclChar, root, pc, ps));
+        CSP_NCCL(ncclRecv(co + co_bytes(p.lo), co_bytes(n), ncclChar, p.dev, rc, rs));
+        if (max_dev) {
+            CSP_NCCL(ncclSend(a + d.o_md + (size_t)off * 8, (size_t)n * 8, ncclChar, root, pc, ps));
+            CSP_NCCL(ncclRecv(max_dev + p.lo, (size_t)n * 8, ncclChar, p.dev, rc, rs));
+        }
+        if (status) {
+            CSP_NCCL(ncclSend(a + d.o_st + (size_t)off * 4, (size_t)n * 4, ncclChar, root, pc, ps));
+            CSP_NCCL(ncclRecv(status + p.lo, (size_t)n * 4, ncclChar, p.dev, rc, rs));
+        }
+        return 0;
+    }
+    int gather_end(int) { if (!node->comms.empty()) CSP_NCCL(ncclGroupEnd()); return 0; }
+    int finish() {
+        for (size_t g = 0; g < dev.size(); ++g) {
+            CSP_HIP(hipSetDevice(node->devs[g]));
+            CSP_HIP(hipStreamSynchronize(node->compute[g]));
+            CSP_HIP(hipStreamSynchronize(node->comm[g]));
+        }
+        return 0;
+    }
+};
+
+// chunks per shard of the device-resident sharded call: the gather of chunk i overlaps the solve of chunk i + 1
+// (CSP_SHARD_CHUNKS overrides; a chunk keeps at least 4096 trajectories)
+int shard_chunks(int64_t per_dev) {
+    static const int forced = [] { const char *e = std::getenv("CSP_SHARD_CHUNKS"); return e ? std::atoi(e) : 0; }();
+    int n = forced > 0 ? forced : 4;
+    while (n > 1 && per_dev / n < 4096) --n;
+    return n;
+}
+
+int solve_sharded_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoints, const void *times, const void *bc,
+                         void *coeffs, double *max_dev, int32_t *status, const std::vector<int> &ordinals, int ngpu) {
+    if (s.ragged) return CSP_ERR_UNSUPPORTED;   // the root-resident form shards uniform batches (ragged ones: host-memory form)
+    // the root is the device that owns the caller's buffers: desc->device_id, or the current device
+    int root_dev = desc->device_id;
+    if (root_dev < 0) CSP_HIP(hipGetDevice(&root_dev));
+    std::vector<int> devs;
+    devs.push_back(root_dev);
+    for (int o : ordinals)
+        if (o != root_dev && (int)devs.size() < ngpu) devs.push_back(o);
+    if ((int)devs.size() != ngpu) return CSP_ERR_INVALID_ARG;
+    bool root_ok = false;
+    for (int o : ordinals) root_ok |= o == root_dev;
+    if (!root_ok) return CSP_ERR_NO_DEVICE;
+    ShardNode *node = nullptr;
+    int rc = shard_node(devs, &node);
+    if (rc != CSP_OK) return rc;
+    CSP_HIP(hipSetDevice(root_dev));
+    CSP_HIP(hipDeviceSynchronize());   // the caller's inputs are complete (the entry takes no stream)
+    RcclTransport t;
+    t.desc = desc; t.s = s; t.node = node; t.root = 0;
+    t.nchunks = shard_chunks(s.B / ngpu);
+    t.wp = (const char *)waypoints; t.tm = (const char *)times; t.bc = (const char *)bc;
+    t.co = (char *)coeffs; t.max_dev = max_dev; t.status = status;
+    const int span_before = g_span_override;
+    g_span_override = use_span(desc, s) ? 1 : 0;   // decided from the WHOLE batch, pinned for the pieces
+    rc = t.setup();
+    if (rc == CSP_OK) rc = csp::shard::run(t, s.B, ngpu, 0, t.nchunks);
+    if (rc != CSP_OK) (void)t.finish();
+    t.teardown();
+    g_span_override = span_before;
+    return rc;
 }
 
 }  // namespace
@@ -362,7 +631,7 @@ int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *wa
     Shape s;
     int rc = validate(desc, s);
     if (rc != CSP_OK) return rc;
-    if (desc->mem_space != CSP_MEM_HOST || (desc->flags & CSP_FLAG_SEGMENT_MAJOR)) return CSP_ERR_INVALID_ARG;
+    if (desc->flags & CSP_FLAG_SEGMENT_MAJOR) return CSP_ERR_INVALID_ARG;
     if (s.B == 0) return CSP_OK;
     if (!waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
     // chunk g runs on the g-th gfx950 device (other architectures may sit between them in HIP's numbering)
@@ -380,6 +649,8 @@ int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *wa
     if (ngpu <= 0) ngpu = have;
     if (ngpu > have) return CSP_ERR_INVALID_ARG;
     if ((int64_t)ngpu > s.B) ngpu = (int)s.B;
+    if (desc->mem_space == CSP_MEM_DEVICE)   // the batch lives on a root device: scatter / solve / gather over RCCL
+        return solve_sharded_device(desc, s, waypoints, times, bc, coeffs, max_dev, status, ordinals, ngpu);
     const int span_choice = use_span(desc, s) ? 1 : 0;   // from the WHOLE batch; pinned for every chunk
     const size_t m = 2 * (size_t)s.order;
     struct Chunk {

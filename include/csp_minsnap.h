@@ -122,13 +122,24 @@ size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
 
 /* The same solve spread over `ngpu` devices of this node from ONE process (the reference planner
  * is a single C++ process).  Trajectories are independent
- * (minimum_snap.cpp has no cross-trajectory term), so the batch is cut into `ngpu` contiguous chunks
- * and chunk g runs on the g-th gfx950 device, each driven by a host thread of its own through that device's cached
- * staging arena (page-locked halves, DMA overlapped with the host copy) -- staging, kernel and copy-back of the
- * chunks proceed concurrently, no collective.  Host memory only (desc->mem_space must be CSP_MEM_HOST;
- * desc->device_id is ignored); synchronous.  ngpu <= 0 uses every gfx950 device; ngpu greater than the device
- * count is CSP_ERR_INVALID_ARG.  The kernel is chosen ONCE from the whole batch and pinned for the chunks, so
- * the results are bit-identical to csp_minsnap_solve_batch on one device. */
+ * (minimum_snap.cpp has no cross-trajectory term), so the batch is cut into `ngpu` contiguous shards, shard g on the
+ * g-th gfx950 device; no collective other than the scatter of inputs and the gather of results.  Synchronous.
+ * ngpu <= 0 uses every gfx950 device; ngpu greater than the device count is CSP_ERR_INVALID_ARG.
+ *   CSP_MEM_HOST   : every shard is staged from / to the caller's host memory by a host thread of its own through that
+ *                    device's cached arena (page-locked halves, DMA overlapped with the host copy); desc->device_id is
+ *                    ignored.  PCIe-bound (1.3-1.55e7 solves/s measured on one device).
+ *   CSP_MEM_DEVICE : the batch is RESIDENT on a root device (desc->device_id, or the current one), uniform batches only
+ *                    (ragged: CSP_ERR_UNSUPPORTED).  Inputs are scattered and coefficients gathered over RCCL / xGMI from
+ *                    that root -- single-process communicators (ncclCommInitAll, cached), grouped ncclSend / ncclRecv,
+ *                    one compute and one communication stream per device; every shard is cut into chunks (4; at least
+ *                    4096 trajectories each; CSP_SHARD_CHUNKS overrides) and the gather of chunk i overlaps the solve of
+ *                    chunk i+1.  The root's own shard is solved in place.  The call first synchronises the root device
+ *                    (it takes no stream).
+ * The span-versus-chunked kernel choice is made ONCE from the whole batch and pinned for the shards / chunks; within the
+ * fixed-size kernels the narrow small-batch variants are bit-equal with the wide ones (tests), so results equal
+ * csp_minsnap_solve_batch on one device bit for bit.  UNVERIFIED ON MORE THAN ONE GPU: the development boxes have one
+ * device -- what runs there is ngpu = 1 (both forms), the chunk / peer schedule over a recording transport on the CPU
+ * (tests/test_shard_schedule.py), and tests that run only where two devices exist. */
 int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                                     const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu);
 

@@ -187,3 +187,65 @@ def test_mixed_entry_edge_cases(csp, oracle_mod):
     assert e.coeff_offsets.shape == (1,)
     with pytest.raises(csp.CspError):
         csp.solve_mixed(orders, wp, tm, off, max_segments=300)
+
+
+def test_sharded_entry_with_a_device_resident_batch(csp):
+    """csp_minsnap_solve_batch_sharded with CSP_MEM_DEVICE: the batch lives on the root GPU and is scattered / solved / gathered
+    over RCCL from one process.  On a one-GPU box this is the ngpu = 1 degenerate path (no communicator; the root's shard cut
+    into chunks and solved in place through the same schedule): bit-equal with the plain call -- fixed kernel (4 chunks),
+    per-trajectory boundary conditions + status + max_dev with the path penalty, the generic kernel (workspace from the
+    arena), the chunked kernel; ragged batches are refused."""
+    import torch
+    rng = np.random.default_rng(9)
+    B, S = 20000, 16
+    wp, tm = synth.make_batch(B, S, config_id=95)
+    d_wp, d_tm = torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda()
+    bc = torch.from_numpy(rng.normal(size=(B, 4, 3))).cuda()
+    for kw in (dict(order=4), dict(order=2, path_weight=1e-3, vel_zero_weight=0.01, bc=bc, want_status=True, want_max_dev=True),
+               dict(order=4, force_generic=True, want_status=True), dict(order=3)):
+        kw = dict(kw)
+        b = kw.pop("bc", None)
+        one = csp.solve_batch(d_wp, d_tm, b, **kw)
+        sh = csp.solve_batch(d_wp, d_tm, b, ngpu=1, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(one.coeffs, sh.coeffs), kw
+        if kw.get("want_status"):
+            assert torch.equal(one.status, sh.status)
+        if kw.get("want_max_dev"):
+            assert torch.equal(one.max_dev, sh.max_dev)
+    wl, tl = synth.make_batch(9000, 40, config_id=96)     # chunked kernel, two chunks
+    a = csp.solve_batch(torch.from_numpy(wl).cuda(), torch.from_numpy(tl).cuda(), order=4)
+    b = csp.solve_batch(torch.from_numpy(wl).cuda(), torch.from_numpy(tl).cuda(), order=4, ngpu=1)
+    torch.cuda.synchronize()
+    assert a.kernel.startswith("chunked_") and torch.equal(a.coeffs, b.coeffs)
+    off = torch.arange(0, 41, 8, dtype=torch.int64).cuda()
+    with pytest.raises(csp.CspError) as ei:
+        csp.solve_batch(d_wp[:45], d_tm.reshape(-1)[:40], order=4, seg_offsets=off, ngpu=1)
+    assert ei.value.code == -2
+    with pytest.raises(csp.CspError):
+        csp.solve_batch(d_wp, d_tm, order=4, ngpu=csp.device_count() + 1)
+
+
+def test_sharding_on_two_devices(csp):
+    """Runs only where two gfx950 devices are visible (never on the development boxes -- the multi-GPU paths are UNVERIFIED on
+    hardware until this has run once): ngpu = 2 through both forms of csp_minsnap_solve_batch_sharded against the one-device
+    result, bit for bit, and bench.py --end-to-end (RootPipeline over RCCL, two ranks)."""
+    import json, os, subprocess, sys
+    import torch
+    if csp.device_count() < 2:
+        pytest.skip("needs two gfx950 devices")
+    B, S = 40000, 16
+    wp, tm = synth.make_batch(B, S, config_id=97)
+    one = csp.solve_batch(wp, tm, order=4, want_status=True)
+    host2 = csp.solve_batch(wp, tm, order=4, want_status=True, ngpu=2)
+    assert np.array_equal(one.coeffs, host2.coeffs) and np.array_equal(one.status, host2.status)
+    dev2 = csp.solve_batch(torch.from_numpy(wp).cuda(), torch.from_numpy(tm).cuda(), order=4, want_status=True, ngpu=2)
+    torch.cuda.synchronize()
+    assert np.array_equal(one.coeffs, dev2.coeffs.cpu().numpy()) and np.array_equal(one.status, dev2.status.cpu().numpy())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192", "--end-to-end",
+                          "--no-side-records", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["end_to_end"]["bit_equal_to_one_device"] is True
