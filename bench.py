@@ -116,6 +116,32 @@ def bench_uniform(csp, dev, B, S, o, steps, warmup, config_id, pw=0.0, vw=0.0, l
     return rec, prep, wp, tm
 
 
+def bench_c2_multi(csp, dev, nb=16):
+    """BASELINE C2 as a planner meets it: `nb` independent 4096-trajectory batches per tick.  One csp_minsnap_solve_multi call =
+    ONE kernel launch for all of them (the workgroups find their batch in a kernel-argument table) against one launch each."""
+    B, S, o = 4096, 8, 4
+    wps, tms = [], []
+    for k in range(nb):
+        wp, tm = synth.make_batch(B, S, config_id=2, offset=k * B)
+        wps.append(torch.from_numpy(wp).to(dev))
+        tms.append(torch.from_numpy(tm).to(dev))
+    pm = csp.PreparedMulti(wps, tms, order=o)
+    ms = timed(pm.run, 100, 10, dev)
+    singles = [csp.PreparedSolve(w, t, order=o) for w, t in zip(wps, tms)]
+
+    def loop():
+        for ps in singles:
+            ps.run()
+    ms_loop = timed(loop, 100, 10, dev)
+    torch.cuda.synchronize(dev)
+    same = all(bool(torch.equal(a, ps.out)) for a, ps in zip(pm.out, singles))
+    nbytes = nb * B * synth.algorithmic_bytes(S, o, 8)
+    return {"workload": "%d independent batches of C2 (B=4096 x 8 segments, order 4, fp64) per step" % nb,
+            "one_call_one_launch_us_per_batch": ms * 1e3 / nb, "one_launch_per_batch_us_per_batch": ms_loop * 1e3 / nb,
+            "solves_per_s": nb * B / (ms * 1e-3), "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "bit_equal_to_single_launches": same}
+
+
 def bench_c5(csp, dev, batch, steps, warmup):
     """BASELINE config C5 -- mixed batch, S ~ U{4..64}, order ~ U{3,4,5}, fp32 storage -- through ONE csp_minsnap_solve_mixed call
     per step: the bucketing by (order, length class) runs on the device INSIDE the timed region, and the coefficients land in
@@ -407,6 +433,7 @@ def main():
                 del p_
                 torch.cuda.empty_cache()
                 res["c2"], p_, _, _ = bench_uniform(csp, dev, 4096, 8, 4, 200, 20, 2, label="C2: B=4096 x 8 segments, order 4, fp64")
+                res["c2_multi"] = bench_c2_multi(csp, dev)
                 res["yaml_default"], p_, _, _ = bench_uniform(
                     csp, dev, 65536, 16, 2, side_steps, 3, 3, pw=1e-7, vw=0.01,
                     label="shipped yaml (minimum_snap_config.yaml:5-10): order 2, vel_zero_weight 0.01, path_weight 1e-7; B=65536 x 16 segments")

@@ -40,7 +40,7 @@ TRAJ_OK, TRAJ_NONFINITE, TRAJ_NOT_SPD, TRAJ_SKIPPED = 0, 1, 2, 4
 
 EXPORTED_SYMBOLS = (
     "csp_minsnap_solve_batch", "csp_minsnap_solve_batch_sharded", "csp_minsnap_workspace_bytes", "csp_minsnap_time_alloc_batch",
-    "csp_minsnap_solve_mixed", "csp_minsnap_mixed_workspace_bytes",
+    "csp_minsnap_solve_mixed", "csp_minsnap_mixed_workspace_bytes", "csp_minsnap_solve_multi",
     "csp_minsnap_plan_batch", "csp_minsnap_plan_workspace_bytes", "csp_minsnap_sample_batch",
     "csp_minsnap_generate_batch", "csp_minsnap_sample_capacity",
     "csp_minsnap_kernel_name", "csp_minsnap_device_count", "csp_minsnap_version",
@@ -84,6 +84,8 @@ _lib.csp_minsnap_solve_batch_sharded.restype = ctypes.c_int
 _lib.csp_minsnap_solve_batch_sharded.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
 _lib.csp_minsnap_workspace_bytes.restype = ctypes.c_size_t
 _lib.csp_minsnap_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
+_lib.csp_minsnap_solve_multi.restype = ctypes.c_int
+_lib.csp_minsnap_solve_multi.argtypes = [ctypes.POINTER(Desc), ctypes.c_int] + [ctypes.c_void_p] * 7
 _lib.csp_minsnap_solve_mixed.restype = ctypes.c_int
 _lib.csp_minsnap_solve_mixed.argtypes = [ctypes.POINTER(Desc)] + [ctypes.c_void_p] * 8 + [ctypes.c_size_t, ctypes.c_void_p]
 _lib.csp_minsnap_mixed_workspace_bytes.restype = ctypes.c_size_t
@@ -309,6 +311,43 @@ def solve_batch(waypoints, times, bc=None, order=4, path_weight=0.0, vel_zero_we
             None, 0, None)
     _check(rc)
     return Result(out, md, stt, kernel_name(desc))
+
+
+class PreparedMulti:
+    """csp_minsnap_solve_multi with everything fixed: `run()` is one C-ABI call -- and one kernel launch for the fixed-size
+    buckets -- over n independent uniform batches of one shape (lists of CUDA tensors [B_k,S+1,3] / [B_k,S])."""
+
+    def __init__(self, waypoints, times, bcs=None, order=4, vel_zero_weight=0.0, want_status=False, stream=None):
+        import torch
+        n = len(waypoints)
+        self.dev, tdt = waypoints[0].device, waypoints[0].dtype
+        S = times[0].shape[1]
+        m = 2 * int(order)
+        self.wp = [w.contiguous() for w in waypoints]
+        self.tm = [t.to(tdt).contiguous() for t in times]
+        zero = torch.zeros((1, 4, 3), dtype=tdt, device=self.dev)
+        self.bc = [zero if (bcs is None or bcs[k] is None) else bcs[k].to(tdt).contiguous().reshape(-1, 4, 3) for k in range(n)]
+        per = self.bc[0].shape[0] != 1
+        self.out = [torch.empty((t.shape[0], S, 3, m), dtype=tdt, device=self.dev) for t in self.tm]
+        self.status = [torch.empty(t.shape[0], dtype=torch.int32, device=self.dev) for t in self.tm] if want_status else None
+        self.desc = make_desc(order, 0, S, DTYPE_F32 if tdt == torch.float32 else DTYPE_F64, 0.0, vel_zero_weight, MEM_DEVICE, per,
+                              device_id=self.dev.index if self.dev.index is not None else -1)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._keep = (arr(self.wp), arr(self.tm), arr(self.bc), arr(self.out), arr(self.status) if want_status else None,
+                      (ctypes.c_int64 * n)(*[t.shape[0] for t in self.tm]))
+        self.n, self._stream = n, stream
+
+    def run(self, stream=None):
+        import torch
+        st = stream if stream is not None else (self._stream if self._stream is not None
+                                                else torch.cuda.current_stream(self.dev).cuda_stream)
+        wp, tm, bc, out, stt, nb = self._keep
+        rc = _lib.csp_minsnap_solve_multi(ctypes.byref(self.desc), self.n, ctypes.cast(nb, ctypes.c_void_p), ctypes.cast(wp, ctypes.c_void_p),
+                                          ctypes.cast(tm, ctypes.c_void_p), ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(out, ctypes.c_void_p),
+                                          ctypes.cast(stt, ctypes.c_void_p) if stt is not None else None, ctypes.c_void_p(st))
+        if rc:
+            _check(rc)
+        return self.out
 
 
 class MixedResult:

@@ -558,6 +558,72 @@ int csp_minsnap_solve_batch(const csp_minsnap_desc *desc, const void *waypoints,
     return CSP_OK;
 }
 
+int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *batches, const void *const *waypoints,
+                            const void *const *times, const void *const *bc, void *const *coeffs, int32_t *const *status,
+                            void *hip_stream) {
+    if (!desc || n < 0) return CSP_ERR_INVALID_ARG;
+    if (n == 0) return CSP_OK;
+    if (!batches || !waypoints || !times || !bc || !coeffs) return CSP_ERR_INVALID_ARG;
+    csp_minsnap_desc d = *desc;
+    int64_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (batches[k] < 0) return CSP_ERR_INVALID_ARG;
+        if (batches[k] && (!waypoints[k] || !times[k] || !bc[k] || !coeffs[k] || (status && !status[k]))) return CSP_ERR_INVALID_ARG;
+        total += batches[k];
+    }
+    d.batch = total;
+    Shape s;
+    int rc = validate(&d, s);
+    if (rc != CSP_OK) return rc;
+    if (d.mem_space != CSP_MEM_DEVICE || s.ragged || d.vel_zero_weight_per_traj) return CSP_ERR_UNSUPPORTED;
+    if (total == 0) return CSP_OK;
+    rc = select_device(d.device_id);
+    if (rc != CSP_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool one_launch = use_fixed(&d, s) && d.path_weight == 0.0 && !(d.flags & CSP_FLAG_SEGMENT_MAJOR);
+    if (!one_launch) {
+        // shapes the table-driven kernels do not serve: one ordinary launch per batch (still one C-ABI call), provided no
+        // workspace is needed
+        for (int k = 0; k < n; ++k) {
+            if (!batches[k]) continue;
+            csp_minsnap_desc dk = d;
+            dk.batch = batches[k];
+            Shape sk;
+            if ((rc = validate(&dk, sk)) != CSP_OK) return rc;
+            if (ws_bytes(&dk, sk, nullptr) != 0) return CSP_ERR_UNSUPPORTED;
+            rc = dispatch(&dk, sk, waypoints[k], times[k], bc[k], coeffs[k], nullptr, status ? status[k] : nullptr, nullptr, nullptr, nullptr, 0, st);
+            if (rc != CSP_OK) return rc;
+        }
+        return CSP_OK;
+    }
+    csp::GenericArgs a;
+    a.wp = a.times = a.bc = nullptr; a.coeffs = nullptr; a.max_dev = nullptr; a.status = nullptr; a.seg_off = nullptr; a.ws = nullptr;
+    a.tstar = nullptr; a.vw_per = nullptr;
+    a.path_weight = 0.0; a.vel_zero_weight = d.vel_zero_weight;
+    a.B = 0; a.S = s.S; a.order = s.order; a.bc_per_traj = d.bc_per_trajectory ? 1 : 0;
+    a.seg_major = 0; a.Btotal = 0; a.Boffset = 0; a.persistent = 0; a.skip = nullptr; a.tau_mode = 0;
+    for (int k0 = 0; k0 < n; k0 += 32) {
+        csp::MultiTable mt;
+        int slices = 0;
+        mt.n = 0;
+        for (int k = k0; k < n && k < k0 + 32; ++k) {
+            if (!batches[k]) continue;
+            if ((((uintptr_t)waypoints[k] | (uintptr_t)times[k] | (uintptr_t)coeffs[k]) & 15u) != 0) return CSP_ERR_INVALID_ARG;
+            csp::MultiEntry &e = mt.e[mt.n];
+            e.wp = waypoints[k]; e.tm = times[k]; e.bc = bc[k]; e.co = coeffs[k]; e.status = status ? status[k] : nullptr; e.B = batches[k];
+            mt.first_slice[mt.n] = slices;
+            slices += (int)((batches[k] + 63) / 64);
+            ++mt.n;
+        }
+        if (!mt.n) continue;
+        mt.first_slice[mt.n] = slices;
+        a.multi = &mt;
+        hipError_t e = csp::launch_fixed(a, st);
+        if (e != hipSuccess) return hip_fail(e, "multi launch");
+    }
+    return CSP_OK;
+}
+
 size_t csp_minsnap_mixed_workspace_bytes(const csp_minsnap_desc *desc) {
     if (!desc || desc->batch < 0) return 0;
     return csp::mixed_workspace_bytes(desc->batch);

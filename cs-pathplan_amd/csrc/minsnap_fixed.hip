@@ -41,7 +41,7 @@ const char *fixed_kernel_name(int order, int S, bool path) {
 }
 
 hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
-    if (a.B == 0) return hipSuccess;
+    if (a.B == 0 && !a.multi) return hipSuccess;
     if (a.path_weight > 0.0) {
         // the kernel writes status and max_dev itself, and only for trajectories not marked in `skip`
         switch (a.order) {
@@ -52,10 +52,10 @@ hipError_t launch_fixed(const GenericArgs &a, hipStream_t st) {
         return hipErrorInvalidValue;
     }
     hipError_t e;
-    if (a.status && (e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.B, st)) != hipSuccess) return e;
+    if (a.status && !a.multi && (e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.B, st)) != hipSuccess) return e;
     // without the path penalty the reference's deviation metric is evaluated at t* = 0, where the
     // polynomial equals its waypoint exactly (minimum_snap.cpp:342, :596-617)
-    if (a.max_dev && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
+    if (a.max_dev && !a.multi && (e = hipMemsetAsync(a.max_dev, 0, sizeof(double) * (size_t)a.B, st)) != hipSuccess) return e;
     // persistent grid: two workgroups per CU (register- and LDS-limited residency of these kernels)
     static int cus = 0;
     if (cus == 0) {

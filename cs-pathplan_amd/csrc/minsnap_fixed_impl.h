@@ -623,7 +623,7 @@ __device__ __forceinline__ void fixed_body(const GenericArgs &a, int64_t b0, int
 // FULL = every workgroup owns 64 real trajectories (B % 64 == 0); the ragged remainder of a
 // batch is a second, single-workgroup launch of the FULL=false variant.
 template <int O, int S, bool STATUS, bool FULL, bool SEGMAJ, int NAX = 3>
-__global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
+__global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a, MultiTable mt) {
     using L = FixedLds<O, S>;
     __shared__ __attribute__((aligned(16))) double lds[L::TOTAL_DOUBLES];
     double *l_wp = lds;
@@ -636,8 +636,22 @@ __global__ void __launch_bounds__(128) minsnap_fixed_kernel(GenericArgs a) {
     // FULL: 64 trajectories per workgroup; otherwise a.slice_w (<= 64) of them -- the ragged tail of a batch, or a small
     // batch cut into narrow slices (lanes >= rows compute on an unloaded image and store nothing)
     const int slice_w = FULL ? 64 : a.slice_w;
-    const int64_t b0 = (int64_t)blockIdx.x * slice_w;
+    int64_t blk = blockIdx.x;
+    if (!FULL && mt.n) {
+        // csp_minsnap_solve_multi: this workgroup's batch (scalar search of the kernel-argument table), whose buffers replace
+        // the launch-wide ones
+        int k = 0;
+        while (k + 1 < mt.n && (int)blockIdx.x >= mt.first_slice[k + 1]) ++k;
+        blk -= mt.first_slice[k];
+        a.wp = mt.e[k].wp; a.times = mt.e[k].tm; a.bc = mt.e[k].bc; a.coeffs = mt.e[k].co; a.status = mt.e[k].status; a.B = mt.e[k].B;
+    }
+    const int64_t b0 = blk * slice_w;
     const int rows = (int)((a.B - b0) < slice_w ? (a.B - b0) : slice_w);
+    if (!FULL && STATUS && mt.n) {
+        // one launch, many status arrays: cleared here instead of by a memset per batch (the __syncthreads below orders
+        // these stores before the atomicOr of either role)
+        if (role == 0 && lane < rows && NAX == 3) a.status[b0 + lane] = 0;
+    }
 
     CSP_STAMP_RT(5);
     CSP_STAMP(0);
@@ -853,6 +867,19 @@ inline int nt_stores_for(int64_t B, int S, int O) {
 template <int O, int S, bool SEGMAJ_OK>
 hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
     const dim3 block(128);
+    if (a.multi) {
+        // csp_minsnap_solve_multi: every batch cut into slices of 64 (one lane per trajectory), one workgroup per slice,
+        // all of them in one grid
+        GenericArgs t = a;
+        t.slice_w = 64;
+        t.multi = nullptr;
+        const dim3 grid((unsigned)a.multi->first_slice[a.multi->n]);
+        bool any_status = false;
+        for (int k = 0; k < a.multi->n; ++k) any_status |= a.multi->e[k].status != nullptr;
+        if (any_status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false>), grid, block, 0, st, t, *a.multi);
+        else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false>), grid, block, 0, st, t, *a.multi);
+        return hipGetLastError();
+    }
     const bool axis_ok = O == 4 && !a.seg_major && axis_lanes_enabled();
     const int w = narrow_slice(a.B, cus, axis_ok);
     if (w < 64 && !a.seg_major) {
@@ -862,13 +889,13 @@ hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
         if constexpr (O == 4) {
             // slices of <= 16 trajectories: three lanes per trajectory, one per axis (fixed_body NAX = 1)
             if (w <= 16 && axis_ok) {
-                if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false, 1>), grid, block, 0, st, t);
-                else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false, 1>), grid, block, 0, st, t);
+                if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false, 1>), grid, block, 0, st, t, MultiTable{});
+                else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false, 1>), grid, block, 0, st, t, MultiTable{});
                 return hipGetLastError();
             }
         }
-        if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false>), grid, block, 0, st, t);
-        else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false>), grid, block, 0, st, t);
+        if (a.status) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, true, false, false>), grid, block, 0, st, t, MultiTable{});
+        else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, false, false, false>), grid, block, 0, st, t, MultiTable{});
         return hipGetLastError();
     }
     const int64_t n_full = a.B / 64, rem = a.B % 64;
@@ -897,9 +924,9 @@ hipError_t launch_s(const GenericArgs &a, int cus, hipStream_t st) {
             constexpr bool WHOLE_LINES = !SM && (O == 4 || LineGeom<O, S>::OK);
             f.nt_stores = (WHOLE_LINES || O == 4) ? nt_stores_for(a.B, S, O) : (nt_forced() == 1 ? 1 : 0);
             if (a.persistent && !a.bc_per_traj && !a.vw_per) hipLaunchKernelGGL((minsnap_fixed_persistent_kernel<O, S, ST, SM>), dim3((unsigned)pgrid), block, 0, st, f, (int)n_full);
-            else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f);
+            else hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, true, SM>), dim3((unsigned)n_full), block, 0, st, f, MultiTable{});
         }
-        if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, false, SM>), dim3(1), block, 0, st, t);
+        if (rem) hipLaunchKernelGGL((minsnap_fixed_kernel<O, S, ST, false, SM>), dim3(1), block, 0, st, t, MultiTable{});
     };
     if (a.seg_major) {
         if constexpr (SEGMAJ_OK) {

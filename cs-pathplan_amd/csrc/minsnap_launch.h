@@ -9,6 +9,20 @@
 
 namespace csp {
 
+// csp_minsnap_solve_multi: up to 32 independent uniform batches of one shape in ONE launch of the fixed-size kernels; a
+// workgroup finds its (batch, slice) from first_slice[] -- passed BY VALUE as a kernel argument (no table upload)
+struct MultiEntry {
+    const void *wp, *tm, *bc;
+    void *co;
+    int32_t *status;
+    int64_t B;
+};
+struct MultiTable {
+    int n = 0;                 // 0: an ordinary single-batch launch
+    int first_slice[33];       // first workgroup of batch k; [n] = the grid size
+    MultiEntry e[32];
+};
+
 struct GenericArgs {
     const void *wp;         // [B][S+1][3] (or ragged concatenation)
     const void *times;      // [B][S]
@@ -36,6 +50,8 @@ struct GenericArgs {
                             // are cut into narrower slices so that every CU gets one, see fixedk::narrow_slice)
     int nt_stores = 0;      // fixed kernels, whole slices: non-temporal coefficient stores -- set by the launcher for
                             // batches whose coefficients exceed the Infinity Cache (fixedk::store16)
+    const MultiTable *multi = nullptr;   // HOST pointer, launcher only: csp_minsnap_solve_multi's batches (then wp/times/bc/coeffs/
+                                         // status/B above are ignored)
 };
 
 hipError_t launch_generic(const GenericArgs &a, bool f32, bool f32_arith, hipStream_t st);

@@ -143,6 +143,22 @@ size_t csp_minsnap_workspace_bytes(const csp_minsnap_desc *desc);
 int csp_minsnap_solve_batch_sharded(const csp_minsnap_desc *desc, const void *waypoints, const void *times,
                                     const void *bc, void *coeffs, double *max_dev, int32_t *status, int ngpu);
 
+/* n INDEPENDENT uniform batches of one shape (same order, segment count, dtype, weights, flags: `desc`; desc->batch is
+ * ignored) with their own buffers, in ONE call -- and, for the shapes of the register-resident fixed-size kernels without
+ * the path penalty, in ONE kernel launch: a launch costs ~3 us of dispatch / first-load / end-of-kernel latency around the
+ * 3 us of work of a 4096-trajectory batch (BASELINE config 2), so a planner that solves many small batches per tick pays
+ * mostly launches.  The workgroups find their (batch, slice) in a table passed as a kernel argument (no upload).
+ * The reference solves one flight per call (TrajectoryGeneratorTool::SolveQPClosedForm, math_util/minimum_snap.hpp:45-53).
+ *   batches[k]            : trajectories of batch k
+ *   waypoints/times/bc/coeffs[k] : batch k's buffers, layouts as csp_minsnap_solve_batch (bc [1][4][3] or [B_k][4][3])
+ *   status                : NULL, or n pointers to [B_k] int32 arrays (all or none)
+ * CSP_MEM_DEVICE only (CSP_ERR_UNSUPPORTED otherwise, as for ragged descriptors and per-trajectory weights); other shapes
+ * are served by one ordinary launch per batch when they need no workspace.  Results equal csp_minsnap_solve_batch's per
+ * batch bit for bit.  Asynchronous on `hip_stream`. */
+int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *batches, const void *const *waypoints,
+                            const void *const *times, const void *const *bc, void *const *coeffs, int32_t *const *status,
+                            void *hip_stream);
+
 /* Mixed-ORDER ragged batches in ONE call (BASELINE config 5: per-trajectory segment count AND derivative order).  The
  * reference solves one flight per call with one `order` (TrajectoryGeneratorTool::SolveQPClosedForm,
  * math_util/minimum_snap.hpp:45-53); a planner that batches flights of different smoothness classes would otherwise have to

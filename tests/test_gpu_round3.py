@@ -249,3 +249,40 @@ def test_sharding_on_two_devices(csp):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["end_to_end"]["bit_equal_to_one_device"] is True
+
+
+@pytest.mark.parametrize("order,S", [(4, 8), (2, 16), (3, 5), (5, 8)])
+def test_many_small_batches_in_one_launch(csp, order, S):
+    """csp_minsnap_solve_multi: independent uniform batches of one shape, each with its own buffers, boundary conditions and
+    status array, in one kernel launch (fixed-size kernels; table passed as a kernel argument).  Bit-equal with one
+    csp_minsnap_solve_batch call per batch; batch sizes around the 64-trajectory slice, empty batches, more than 32 batches
+    (two launches), a bad trajectory flagged in the right batch."""
+    import torch
+    rng = np.random.default_rng(order * 31 + S)
+    sizes = [4096, 1, 63, 64, 65, 0, 200, 1000] + [rng.integers(1, 300) for _ in range(30)]
+    wps, tms, bcs = [], [], []
+    for k, B in enumerate(sizes):
+        wp, tm = synth.make_batch(max(int(B), 1), S, config_id=110 + order, offset=1000 * k)
+        wps.append(torch.from_numpy(wp[:B]).cuda())
+        tms.append(torch.from_numpy(tm[:B]).cuda())
+        bcs.append(torch.from_numpy(rng.normal(size=(1, 4, 3))).cuda())
+    tms[6][17, 2] = float("nan")
+    pm = csp.PreparedMulti(wps, tms, bcs, order=order, vel_zero_weight=0.02, want_status=True)
+    for o in pm.out:
+        o.fill_(7.0)
+    pm.run()
+    torch.cuda.synchronize()
+    for k, B in enumerate(sizes):
+        if B == 0:
+            continue
+        one = csp.solve_batch(wps[k], tms[k], bcs[k], order=order, vel_zero_weight=0.02, want_status=True)
+        torch.cuda.synchronize()
+        if k == 6:
+            assert int(pm.status[k][17]) & csp.TRAJ_NONFINITE and int(pm.status[k].abs().sum()) == int(pm.status[k][17])
+            ok = torch.ones(B, dtype=torch.bool, device="cuda")
+            ok[17] = False
+            assert torch.equal(pm.out[k][ok], one.coeffs[ok]), k
+        else:
+            assert torch.equal(pm.out[k], one.coeffs), (k, B)
+            assert int(pm.status[k].abs().max()) == 0
+        assert torch.equal(pm.status[k], one.status), k
