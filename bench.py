@@ -22,7 +22,10 @@ Side records on the same line (N=1 only; `--no-side-records` skips them), each t
   c2            BASELINE C2 (B=4096, S=8): the small-batch launch
   yaml_default  the reference's shipped configuration (minimum_snap_config.yaml:5-10: order 2,
                 vel_zero_weight 0.01, path_weight 1e-7) at B=65536, S=16 -- the path-penalty kernel
-  c5            BASELINE C5: mixed ragged batch, S~U{4..64}, order~U{3,4,5}, fp32 storage
+  c2_multi      16 such batches per step in ONE csp_minsnap_solve_multi call / kernel launch
+  sample        row N1: sampling + thinning + statistics of a resident B=65536 x 16 batch (csp_minsnap_sample_batch)
+  c5            BASELINE C5: mixed ragged batch, S~U{4..64}, order~U{3,4,5}, fp32 storage, ONE csp_minsnap_solve_mixed call
+                (device-side bucketing inside the timed region)
   single_flight ONE flight (README uav31_0, the reference's own call pattern) through the C++ class shim,
                 plan + sample, with the CPU oracle's GenerateTrajectoryMatrix time beside it
 `--end-to-end` (N>=1) adds the root-scatter / solve / root-gather pipeline over RCCL.
@@ -140,6 +143,25 @@ def bench_c2_multi(csp, dev, nb=16):
             "one_call_one_launch_us_per_batch": ms * 1e3 / nb, "one_launch_per_batch_us_per_batch": ms_loop * 1e3 / nb,
             "solves_per_s": nb * B / (ms * 1e-3), "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "bit_equal_to_single_launches": same}
+
+
+def bench_sample(csp, dev, B=65536, S=16, order=4):
+    """Row N1: the sampling half of GenerateTrajectoryMatrix (minimum_snap.cpp:97-205) for a resident batch --
+    candidates at dt = min(0.1, T/10), sequential distance thinning, end-point rule, statistics.  Bytes = coefficients and
+    times in + kept samples, counts and statistics out."""
+    wp, _ = synth.make_batch(B, S, config_id=21)
+    d_wp = torch.from_numpy(wp * 4.0).to(dev)
+    plan = csp.plan_batch(d_wp, 5.0, 0.1, order=order, vel_zero_weight=0.02)
+    cap = 256
+    bufs = csp.sample_batch(plan.times, plan.coeffs, 0.7, cap)
+    ms = timed(lambda: csp.sample_batch(plan.times, plan.coeffs, 0.7, cap, out=bufs), 20, 3, dev)
+    samples, counts, stats = bufs
+    kept = int(counts.sum().item())
+    nbytes = B * S * (3 * 2 * order + 1) * 8 + kept * 24 + B * (4 + 16)
+    return {"workload": "sampling + thinning + statistics of B=%d x %d segments, order %d, fp64 (sample_distance 0.7, capacity %d)" % (B, S, order, cap),
+            "kernel_ms": ms, "trajectories_per_s": B / (ms * 1e-3), "mean_samples_kept": kept / B, "max_samples_kept": int(counts.max().item()),
+            "algorithmic_bytes_per_launch": nbytes, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
 
 def bench_c5(csp, dev, batch, steps, warmup):
@@ -434,6 +456,7 @@ def main():
                 torch.cuda.empty_cache()
                 res["c2"], p_, _, _ = bench_uniform(csp, dev, 4096, 8, 4, 200, 20, 2, label="C2: B=4096 x 8 segments, order 4, fp64")
                 res["c2_multi"] = bench_c2_multi(csp, dev)
+                res["sample"] = bench_sample(csp, dev)
                 res["yaml_default"], p_, _, _ = bench_uniform(
                     csp, dev, 65536, 16, 2, side_steps, 3, 3, pw=1e-7, vw=0.01,
                     label="shipped yaml (minimum_snap_config.yaml:5-10): order 2, vel_zero_weight 0.01, path_weight 1e-7; B=65536 x 16 segments")
