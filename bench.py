@@ -24,6 +24,8 @@ Side records on the same line (N=1 only; `--no-side-records` skips them), each t
                 vel_zero_weight 0.01, path_weight 1e-7) at B=65536, S=16 -- the path-penalty kernel
   c2_multi      16 such batches per step in ONE csp_minsnap_solve_multi call / kernel launch
   sample        row N1: sampling + thinning + statistics of a resident B=65536 x 16 batch (csp_minsnap_sample_batch)
+  single_altitude  row N4, the reference's own call: ONE pentadiagonal altitude problem (n = 2000 / 20000) on the GPU (block
+                cyclic reduction) with the CPU oracle's banded Cholesky on one core beside it
   c5            BASELINE C5: mixed ragged batch, S~U{4..64}, order~U{3,4,5}, fp32 storage, ONE csp_minsnap_solve_mixed call
                 (device-side bucketing inside the timed region)
   single_flight ONE flight (README uav31_0, the reference's own call pattern) through the C++ class shim,
@@ -162,6 +164,38 @@ def bench_sample(csp, dev, B=65536, S=16, order=4):
             "kernel_ms": ms, "trajectories_per_s": B / (ms * 1e-3), "mean_samples_kept": kept / B, "max_samples_kept": int(counts.max().item()),
             "algorithmic_bytes_per_launch": nbytes, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
             "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+
+def bench_single_altitude(csp, dev):
+    """Row N4 for the reference's own call pattern: ONE pentadiagonal altitude problem per plan (optimizeHeights,
+    uavPathPlanning.cpp:1575-1713, solve at :1670-1676) -- block cyclic reduction in one workgroup -- with the CPU oracle's
+    banded Cholesky on one core beside it.  GPU times: the kernel on resident data (HIP events) and the whole host-memory
+    C-ABI call (staging included)."""
+    import oracle
+    rng = np.random.default_rng(3)
+    out = {"workload": "one optimizeHeights problem (lambda_smooth 1, lambda_follow 0.5, safe_distance 50, max_climb_rate 2)"}
+    for n in (2000, 20000):
+        xy = np.cumsum(rng.uniform(20, 60, size=(n, 2)), axis=0)
+        z = 100 + np.cumsum(rng.normal(0, 8, n))
+        elev = 80 + 10 * np.sin(np.arange(n) / 5.0) + rng.normal(0, 2, n)
+        xyz = np.column_stack([xy, z])
+        off = np.array([0, n], dtype=np.int64)
+        got = csp.alt_optimize_heights_batch(xyz, elev, off, 1.0, 0.5, 50.0, 2.0)
+        t0 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            csp.alt_optimize_heights_batch(xyz, elev, off, 1.0, 0.5, 50.0, 2.0)
+        host_us = (time.perf_counter() - t0) / reps * 1e6
+        d = [torch.from_numpy(x).to(dev) for x in (xyz, elev, off)]
+        ms = timed(lambda: csp.alt_optimize_heights_batch(d[0], d[1], d[2], 1.0, 0.5, 50.0, 2.0), 20, 3, dev)
+        ref = oracle.alt_optimize(xyz, elev, 1.0, 0.5, 50.0, 2.0, banded=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.alt_optimize(xyz, elev, 1.0, 0.5, 50.0, 2.0, banded=True)
+        cpu_us = (time.perf_counter() - t0) / reps * 1e6
+        out["n_%d" % n] = {"gpu_host_call_us": host_us, "gpu_device_call_us": ms * 1e3, "cpu_banded_cholesky_one_core_us": cpu_us,
+                           "max_rel_err_vs_cpu": float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))}
+    return out
 
 
 def bench_c5(csp, dev, batch, steps, warmup):
@@ -457,6 +491,7 @@ def main():
                 res["c2"], p_, _, _ = bench_uniform(csp, dev, 4096, 8, 4, 200, 20, 2, label="C2: B=4096 x 8 segments, order 4, fp64")
                 res["c2_multi"] = bench_c2_multi(csp, dev)
                 res["sample"] = bench_sample(csp, dev)
+                res["single_altitude"] = bench_single_altitude(csp, dev)
                 res["yaml_default"], p_, _, _ = bench_uniform(
                     csp, dev, 65536, 16, 2, side_steps, 3, 3, pw=1e-7, vw=0.01,
                     label="shipped yaml (minimum_snap_config.yaml:5-10): order 2, vel_zero_weight 0.01, path_weight 1e-7; B=65536 x 16 segments")

@@ -770,15 +770,35 @@ def _alt_params(lambda_smooth, lambda_follow, safe_distance, max_climb_rate):
     return AltParams(float(lambda_smooth), float(lambda_follow), float(safe_distance), float(max_climb_rate))
 
 
+def _alt_ws_bytes(total):
+    _lib.csp_alt_workspace_bytes.restype = ctypes.c_size_t
+    _lib.csp_alt_workspace_bytes.argtypes = [ctypes.c_int64]
+    return int(_lib.csp_alt_workspace_bytes(int(total)))
+
+
 def alt_optimize_heights_batch(xyz, elev, offsets, lambda_smooth=1.0, lambda_follow=0.0, safe_distance=50.0,
                                max_climb_rate=2.0):
-    """Batched UavPathPlanner::optimizeHeights (uavPathPlanning.cpp:1575-1713).  Host (numpy) arrays:
-    xyz [total,3], elev [total] (NaN = no terrain sample), offsets [B+1].  Returns z [total]."""
+    """Batched UavPathPlanner::optimizeHeights (uavPathPlanning.cpp:1575-1713).  numpy arrays (host memory) or torch CUDA
+    tensors (device memory): xyz [total,3], elev [total] (NaN = no terrain sample), offsets [B+1].  Returns z [total]."""
+    p = _alt_params(lambda_smooth, lambda_follow, safe_distance, max_climb_rate)
+    if _is_torch(xyz):
+        import torch
+        dev = xyz.device
+        xyz = xyz.to(torch.float64).contiguous().reshape(-1, 3)
+        elev = elev.to(torch.float64).contiguous()
+        offsets = offsets.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty(xyz.shape[0], dtype=torch.float64, device=dev)
+        need = _alt_ws_bytes(xyz.shape[0])
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        _check(_lib.csp_alt_optimize_heights_batch(xyz.data_ptr(), elev.data_ptr(), offsets.data_ptr(), offsets.numel() - 1, ctypes.byref(p),
+                                                   out.data_ptr(), ws.data_ptr(), need, MEM_DEVICE, dev.index if dev.index is not None else -1,
+                                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.current_stream(dev).synchronize()   # `ws` must outlive the kernel
+        return out
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
     elev = np.ascontiguousarray(elev, dtype=np.float64)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     out = np.empty(xyz.shape[0])
-    p = _alt_params(lambda_smooth, lambda_follow, safe_distance, max_climb_rate)
     _check(_lib.csp_alt_optimize_heights_batch(xyz.ctypes.data, elev.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
                                                ctypes.byref(p), out.ctypes.data, None, 0, MEM_HOST, -1, None))
     return out
@@ -786,13 +806,29 @@ def alt_optimize_heights_batch(xyz, elev, offsets, lambda_smooth=1.0, lambda_fol
 
 def alt_global_smooth_batch(input_z, xyz, offsets, lambda_smooth=1.0, max_climb_rate=2.0):
     """Batched UavPathPlanner::optimizeHeightsGlobalSmooth (uavPathPlanning.cpp:1715-1827).
-    Returns (z [total], solves [B])."""
+    Returns (z [total], solves [B]); numpy (host memory) or torch CUDA tensors (device memory)."""
+    p = _alt_params(lambda_smooth, 0.0, 0.0, max_climb_rate)
+    if _is_torch(xyz):
+        import torch
+        dev = xyz.device
+        xyz = xyz.to(torch.float64).contiguous().reshape(-1, 3)
+        input_z = input_z.to(torch.float64).contiguous()
+        offsets = offsets.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty(xyz.shape[0], dtype=torch.float64, device=dev)
+        solves = torch.empty(offsets.numel() - 1, dtype=torch.int32, device=dev)
+        need = _alt_ws_bytes(xyz.shape[0])
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        _check(_lib.csp_alt_global_smooth_batch(input_z.data_ptr(), xyz.data_ptr(), offsets.data_ptr(), offsets.numel() - 1, ctypes.byref(p),
+                                                out.data_ptr(), solves.data_ptr(), ws.data_ptr(), need, MEM_DEVICE,
+                                                dev.index if dev.index is not None else -1,
+                                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.current_stream(dev).synchronize()
+        return out, solves
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
     input_z = np.ascontiguousarray(input_z, dtype=np.float64)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     out = np.empty(xyz.shape[0])
     solves = np.empty(offsets.shape[0] - 1, dtype=np.int32)
-    p = _alt_params(lambda_smooth, 0.0, 0.0, max_climb_rate)
     _check(_lib.csp_alt_global_smooth_batch(input_z.ctypes.data, xyz.ctypes.data, offsets.ctypes.data, offsets.shape[0] - 1,
                                             ctypes.byref(p), out.ctypes.data, solves.ctypes.data, None, 0, MEM_HOST, -1, None))
     return out, solves

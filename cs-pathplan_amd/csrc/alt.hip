@@ -286,11 +286,220 @@ __global__ void __launch_bounds__(64) alt_global_smooth_wave_kernel(AltArgs a) {
     if (a.solves && lane == 0) a.solves[b] = solves;
 }
 
+
+// ---- ONE (or a few) long problems: block cyclic reduction, one workgroup of 1024 threads per problem ----------------------
+// The reference's own call pattern is ONE pentadiagonal problem per plan (uavPathPlanning.cpp:1670-1676, :1796-1799), where a
+// sequential recurrence -- however it is dealt over lanes -- costs ~0.2 us per row on the device (0.42 ms at n = 2000,
+// 3.7 ms at n = 20000, against tens of microseconds for a banded Cholesky on one CPU core).  Taken two rows at a time the matrix is
+// block TRIDIAGONAL with 2x2 blocks (A_k x_{k-1} + B_k x_k + A_{k+1}^T x_{k+1} = r_k), and cyclic reduction eliminates every
+// other block row per level: log2(n/2) levels forward, as many back, every level parallel over its rows.  Symmetric
+// elimination of an SPD matrix in any order is backward stable, so no pivoting is needed.  A block row keeps 13 doubles
+// (A, symmetric B, r / x, and the coupling C it had when it was eliminated); they live in LDS when the problem fits (n <=
+// ~2800 samples) and in the workspace otherwise.  Different elimination order from the other two mappings: results agree
+// with them to rounding (1e-10 relative measured), not bit for bit.
+struct CrStore {
+    double *p;        // [13][stride]
+    int64_t stride;
+    __device__ __forceinline__ double &at(int q, int64_t k) const { return p[(int64_t)q * stride + k]; }
+};
+enum { CR_A00, CR_A01, CR_A10, CR_A11, CR_B00, CR_B01, CR_B11, CR_R0, CR_R1, CR_C00, CR_C01, CR_C10, CR_C11 };
+
+// y = B^-1 [v0 v1] for the symmetric 2x2 block of row j
+__device__ __forceinline__ void cr_binv(const CrStore &s, int64_t j, double (&inv)[3]) {
+    const double b00 = s.at(CR_B00, j), b01 = s.at(CR_B01, j), b11 = s.at(CR_B11, j);
+    const double rd = rcp64(__builtin_fma(b00, b11, -b01 * b01));
+    inv[0] = b11 * rd; inv[1] = -b01 * rd; inv[2] = b00 * rd;
+}
+
+template <class D, class Rh>
+__device__ __forceinline__ void cr_solve(const CrStore &s, const double *xyz, int64_t n, double sm, double rate, D extra_d, Rh rhs, double *xout) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t N2 = (n + 1) / 2;
+    // ---- assembly: block k = rows 2k, 2k+1 (a missing last row is the identity) ----
+    for (int64_t k = tid; k < N2; k += nt) {
+        double dg[2], e[2], f[2], rr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t i = 2 * k + h;
+            if (i < n) {
+                const double wp = i >= 1 ? edge_w(xyz, i - 1, rate) : 0.0, wn = i + 1 < n ? edge_w(xyz, i, rate) : 0.0;
+                double diag;
+                band_row(xyz, n, i, sm, rate, wp, wn, diag, e[h], f[h]);
+                dg[h] = diag + (extra_d(i) + 1e-8);
+                rr[h] = rhs(i);
+            } else {
+                dg[h] = 1.0; e[h] = 0.0; f[h] = 0.0; rr[h] = 0.0;
+            }
+        }
+        // A_k couples (2k, 2k+1) to (2k-2, 2k-1): [[f_2k, e_2k], [0, f_2k+1]];  B_k = [[d_2k, e_2k+1], [e_2k+1, d_2k+1]]
+        s.at(CR_A00, k) = k ? f[0] : 0.0; s.at(CR_A01, k) = k ? e[0] : 0.0; s.at(CR_A10, k) = 0.0; s.at(CR_A11, k) = k ? f[1] : 0.0;
+        s.at(CR_B00, k) = dg[0]; s.at(CR_B01, k) = e[1]; s.at(CR_B11, k) = dg[1];
+        s.at(CR_R0, k) = rr[0]; s.at(CR_R1, k) = rr[1];
+    }
+    __syncthreads();
+    // ---- forward: at stride st the rows that are odd multiples of st leave; the even multiples absorb them ----
+    int64_t st = 1;
+    for (; st < N2; st <<= 1) {
+        for (int64_t i = (int64_t)tid * 2 * st; i < N2; i += (int64_t)nt * 2 * st) {
+            const int64_t jl = i - st, jr = i + st;
+            double b00 = s.at(CR_B00, i), b01 = s.at(CR_B01, i), b11 = s.at(CR_B11, i), r0 = s.at(CR_R0, i), r1 = s.at(CR_R1, i);
+            double na[4] = {0.0, 0.0, 0.0, 0.0};
+            if (jl >= 0) {
+                const double a00 = s.at(CR_A00, i), a01 = s.at(CR_A01, i), a10 = s.at(CR_A10, i), a11 = s.at(CR_A11, i);   // A_i: i <- jl
+                // the leaving row jl keeps its coupling to me: C_jl = A_i^T
+                s.at(CR_C00, jl) = a00; s.at(CR_C01, jl) = a10; s.at(CR_C10, jl) = a01; s.at(CR_C11, jl) = a11;
+                double iv[3];
+                cr_binv(s, jl, iv);
+                // G = A_i B_jl^-1
+                const double g00 = a00 * iv[0] + a01 * iv[1], g01 = a00 * iv[1] + a01 * iv[2];
+                const double g10 = a10 * iv[0] + a11 * iv[1], g11 = a10 * iv[1] + a11 * iv[2];
+                // B_i -= G A_i^T ; r_i -= G r_jl ; A'_i = -G A_jl
+                b00 -= g00 * a00 + g01 * a01; b01 -= g00 * a10 + g01 * a11; b11 -= g10 * a10 + g11 * a11;
+                const double q0 = s.at(CR_R0, jl), q1 = s.at(CR_R1, jl);
+                r0 -= g00 * q0 + g01 * q1; r1 -= g10 * q0 + g11 * q1;
+                if (jl - st >= 0) {
+                    const double c00 = s.at(CR_A00, jl), c01 = s.at(CR_A01, jl), c10 = s.at(CR_A10, jl), c11 = s.at(CR_A11, jl);
+                    na[0] = -(g00 * c00 + g01 * c10); na[1] = -(g00 * c01 + g01 * c11);
+                    na[2] = -(g10 * c00 + g11 * c10); na[3] = -(g10 * c01 + g11 * c11);
+                }
+            }
+            if (jr < N2) {
+                const double a00 = s.at(CR_A00, jr), a01 = s.at(CR_A01, jr), a10 = s.at(CR_A10, jr), a11 = s.at(CR_A11, jr);   // A_jr: jr <- i
+                double iv[3];
+                cr_binv(s, jr, iv);
+                // G = A_jr^T B_jr^-1 ; B_i -= G A_jr ; r_i -= G r_jr
+                const double g00 = a00 * iv[0] + a10 * iv[1], g01 = a00 * iv[1] + a10 * iv[2];
+                const double g10 = a01 * iv[0] + a11 * iv[1], g11 = a01 * iv[1] + a11 * iv[2];
+                b00 -= g00 * a00 + g01 * a10; b01 -= g00 * a01 + g01 * a11; b11 -= g10 * a01 + g11 * a11;
+                const double q0 = s.at(CR_R0, jr), q1 = s.at(CR_R1, jr);
+                r0 -= g00 * q0 + g01 * q1; r1 -= g10 * q0 + g11 * q1;
+            }
+            s.at(CR_B00, i) = b00; s.at(CR_B01, i) = b01; s.at(CR_B11, i) = b11; s.at(CR_R0, i) = r0; s.at(CR_R1, i) = r1;
+            s.at(CR_A00, i) = na[0]; s.at(CR_A01, i) = na[1]; s.at(CR_A10, i) = na[2]; s.at(CR_A11, i) = na[3];
+        }
+        __syncthreads();
+    }
+    // ---- the last row standing ----
+    if (tid == 0) {
+        double iv[3];
+        cr_binv(s, 0, iv);
+        const double q0 = s.at(CR_R0, 0), q1 = s.at(CR_R1, 0);
+        s.at(CR_R0, 0) = iv[0] * q0 + iv[1] * q1; s.at(CR_R1, 0) = iv[1] * q0 + iv[2] * q1;
+    }
+    __syncthreads();
+    // ---- back-substitution: the rows that left at stride st, from their two neighbours' solutions (kept in R) ----
+    for (st >>= 1; st >= 1; st >>= 1) {
+        for (int64_t j = st + (int64_t)tid * 2 * st; j < N2; j += (int64_t)nt * 2 * st) {
+            double r0 = s.at(CR_R0, j), r1 = s.at(CR_R1, j);
+            {   // x_{j-st}: always exists
+                const double x0 = s.at(CR_R0, j - st), x1 = s.at(CR_R1, j - st);
+                r0 -= s.at(CR_A00, j) * x0 + s.at(CR_A01, j) * x1; r1 -= s.at(CR_A10, j) * x0 + s.at(CR_A11, j) * x1;
+            }
+            if (j + st < N2) {
+                const double x0 = s.at(CR_R0, j + st), x1 = s.at(CR_R1, j + st);
+                r0 -= s.at(CR_C00, j) * x0 + s.at(CR_C01, j) * x1; r1 -= s.at(CR_C10, j) * x0 + s.at(CR_C11, j) * x1;
+            }
+            double iv[3];
+            cr_binv(s, j, iv);
+            s.at(CR_R0, j) = iv[0] * r0 + iv[1] * r1; s.at(CR_R1, j) = iv[1] * r0 + iv[2] * r1;
+        }
+        __syncthreads();
+    }
+    for (int64_t i = tid; i < n; i += nt) xout[i] = s.at((i & 1) ? CR_R1 : CR_R0, i >> 1);
+    __syncthreads();
+}
+
+constexpr int kCrThreads = 1024;
+constexpr size_t kCrLdsBytes = 148 * 1024;   // dynamic LDS of the cyclic-reduction kernels (a problem of <= ~2900 samples fits)
+
+__device__ __forceinline__ CrStore cr_store(double *lds, double *ws_cr, int64_t n) {
+    const int64_t N2 = (n + 1) / 2;
+    const bool fits = (size_t)N2 * 13 * 8 <= kCrLdsBytes;
+    return CrStore{fits ? lds : ws_cr, N2};
+}
+
+// workspace of problem b for the cyclic-reduction kernels: 14 doubles per sample (13 per block row = 6.5 per sample, the
+// solution, the active flags)
+__global__ void __launch_bounds__(kCrThreads) alt_optimize_cr_kernel(AltArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    const int64_t b = blockIdx.x;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) return;
+    const double *xyz = a.xyz + o * 3, *elev = a.a + o;
+    double *ws = a.ws + o * 14, *out = a.out + o;
+    double *x = ws, *store = ws + 2 * ((n + 1) / 2) + 2;
+    const csp_alt_params p = a.p;
+    cr_solve(cr_store(dyn_lds, store, n), xyz, n, p.lambda_smooth, p.max_climb_rate,
+             [&](int64_t i) { return isnan(elev[i]) ? 0.0 : p.lambda_follow; },
+             [&](int64_t i) {
+                 if (isnan(elev[i])) return 0.0;
+                 const double safe_h = elev[i] + p.safe_distance;
+                 return p.lambda_follow * fmax(xyz[i * 3 + 2], safe_h);
+             }, x);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        double z = x[i];
+        if (!isnan(elev[i]) && z < elev[i] + p.safe_distance) z = elev[i] + p.safe_distance;
+        out[i] = z;
+    }
+}
+
+__global__ void __launch_bounds__(kCrThreads) alt_global_smooth_cr_kernel(AltArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    __shared__ int any_violation;
+    const int64_t b = blockIdx.x;
+    const int64_t o = a.off[b], n = a.off[b + 1] - o;
+    if (n <= 0) { if (a.solves && threadIdx.x == 0) a.solves[b] = 0; return; }
+    const double *xyz = a.xyz + o * 3, *zin = a.a + o;
+    double *ws = a.ws + o * 14, *out = a.out + o;
+    const int64_t N2 = (n + 1) / 2;
+    double *x = ws, *act = ws + 2 * N2 + 2 + 13 * N2;     // solution | block rows | active flags
+    double *store = ws + 2 * N2 + 2;
+    const csp_alt_params p = a.p;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) act[i] = 0.0;
+    __syncthreads();
+    int solves = 0;
+    for (int iter = 0; iter < 10; ++iter) {
+        cr_solve(cr_store(dyn_lds, store, n), xyz, n, p.lambda_smooth, p.max_climb_rate,
+                 [&](int64_t i) { return (i == 0 || i == n - 1) ? 1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0) : (act[i] != 0.0 ? 1e8 : 0.0); },
+                 [&](int64_t i) { return (i == 0 || i == n - 1) ? (1e10 + ((i == 0 && i == n - 1) ? 1e10 : 0.0)) * zin[i]
+                                                                : (act[i] != 0.0 ? 1e8 * zin[i] : 0.0); }, x);
+        ++solves;
+        if (threadIdx.x == 0) any_violation = 0;
+        __syncthreads();
+        bool violation = false;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+            if (x[i] < zin[i] - 1e-3 && act[i] == 0.0) { act[i] = 1.0; violation = true; }
+        if (violation) any_violation = 1;
+        __syncthreads();
+        const int v = any_violation;
+        __syncthreads();
+        if (!v) break;
+    }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = fmax(x[i], zin[i]);
+    if (a.solves && threadIdx.x == 0) a.solves[b] = solves;
+}
+
 // fewer problems than this: one wave per problem (the lanes prepare 64 rows at once); more: one lane per problem
 constexpr int64_t kWaveBatch = 2048;
 
-template <typename K, typename KW>
-int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int64_t *offsets, int64_t batch, const csp_alt_params *p,
+// a few LONG problems (the reference's own call: one): block cyclic reduction, one 1024-thread workgroup per problem
+constexpr int64_t kCrMaxBatch = 64, kCrMinAvgSamples = 512;
+inline bool use_cr(int64_t batch, int64_t total) { return batch <= kCrMaxBatch && total >= batch * kCrMinAvgSamples; }
+
+template <typename KC>
+hipError_t launch_cr(KC cr_kernel, const AltArgs &a, hipStream_t st) {
+    static bool attr_done = false;   // > 64 KB of dynamic LDS needs the opt-in, once per kernel (this function is one per kernel)
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCrLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(cr_kernel, dim3((unsigned)a.B), dim3(kCrThreads), kCrLdsBytes, st, a);
+    return hipGetLastError();
+}
+
+template <typename K, typename KW, typename KC>
+int run(K kernel, KW wave_kernel, KC cr_kernel, const double *a0, const double *xyz, const int64_t *offsets, int64_t batch, const csp_alt_params *p,
         double *out, int32_t *solves, void *workspace, size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *stream) {
     if (batch < 0 || !p || (batch > 0 && (!a0 || !xyz || !offsets || !out))) return CSP_ERR_INVALID_ARG;
     if (batch == 0) return CSP_OK;
@@ -305,6 +514,7 @@ int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int
         if (hipMemcpyAsync(&total, offsets + batch, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return CSP_ERR_HIP;
         if (!workspace || workspace_bytes < csp_alt_workspace_bytes(total)) return CSP_ERR_WORKSPACE;
         a.a = a0; a.xyz = xyz; a.off = offsets; a.out = out; a.solves = solves; a.ws = (double *)workspace;
+        if (use_cr(batch, total)) return launch_cr(cr_kernel, a, st) == hipSuccess ? CSP_OK : CSP_ERR_HIP;
         if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
         return hipGetLastError() == hipSuccess ? CSP_OK : CSP_ERR_HIP;
@@ -316,11 +526,12 @@ int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int
     csp::HostCall hc(cur, st);
     const size_t o_a = hc.in(a0, (size_t)total * 8), o_xyz = hc.in(xyz, (size_t)total * 24), o_off = hc.in(offsets, (size_t)(batch + 1) * 8);
     const size_t o_out = hc.out(out, (size_t)total * 8), o_sv = hc.out(solves, (size_t)batch * 4);
-    const size_t o_ws = hc.scratch(csp_alt_workspace_bytes(total) + 8);
+    const size_t o_ws = hc.scratch(csp_alt_workspace_bytes(total) + 8);   // (offsets of a problem's region: o * 14 doubles)
     if (hc.upload() != hipSuccess) return CSP_ERR_HIP;
     a.a = hc.ptr<const double>(o_a); a.xyz = hc.ptr<const double>(o_xyz); a.off = hc.ptr<const int64_t>(o_off);
     a.out = hc.ptr<double>(o_out); a.solves = hc.ptr<int32_t>(o_sv); a.ws = hc.ptr<double>(o_ws);
-    if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
+    if (use_cr(batch, total)) { if (launch_cr(cr_kernel, a, st) != hipSuccess) return CSP_ERR_HIP; }
+    else if (batch < kWaveBatch) hipLaunchKernelGGL(wave_kernel, dim3((unsigned)batch), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, a);
     if (hipGetLastError() != hipSuccess || hc.download() != hipSuccess) return CSP_ERR_HIP;
     return CSP_OK;
@@ -328,18 +539,20 @@ int run(K kernel, KW wave_kernel, const double *a0, const double *xyz, const int
 
 }  // namespace
 
-extern "C" size_t csp_alt_workspace_bytes(int64_t total_points) { return total_points > 0 ? (size_t)total_points * 32 : 0; }
+// 4 doubles per sample for the recurrence kernels; the cyclic-reduction kernels (a few long problems) keep 13 doubles per
+// PAIR of samples, the solution and the active flags: 14 doubles per sample + slack covers both
+extern "C" size_t csp_alt_workspace_bytes(int64_t total_points) { return total_points > 0 ? (size_t)total_points * 14 * 8 + 4096 : 0; }
 
 extern "C" int csp_alt_optimize_heights_batch(const double *xyz, const double *elev, const int64_t *offsets, int64_t batch,
                                               const csp_alt_params *params, double *out_z, void *workspace,
                                               size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
-    return run(alt_optimize_kernel, alt_optimize_wave_kernel, elev, xyz, offsets, batch, params, out_z, nullptr, workspace, workspace_bytes, mem_space,
+    return run(alt_optimize_kernel, alt_optimize_wave_kernel, alt_optimize_cr_kernel, elev, xyz, offsets, batch, params, out_z, nullptr, workspace, workspace_bytes, mem_space,
                device_id, hip_stream);
 }
 
 extern "C" int csp_alt_global_smooth_batch(const double *input_z, const double *xyz, const int64_t *offsets, int64_t batch,
                                            const csp_alt_params *params, double *out_z, int32_t *solves, void *workspace,
                                            size_t workspace_bytes, uint32_t mem_space, int32_t device_id, void *hip_stream) {
-    return run(alt_global_smooth_kernel, alt_global_smooth_wave_kernel, input_z, xyz, offsets, batch, params, out_z, solves, workspace, workspace_bytes,
+    return run(alt_global_smooth_kernel, alt_global_smooth_wave_kernel, alt_global_smooth_cr_kernel, input_z, xyz, offsets, batch, params, out_z, solves, workspace, workspace_bytes,
                mem_space, device_id, hip_stream);
 }

@@ -59,6 +59,10 @@ def lib():
         L.csp_oracle_alt_optimize.argtypes = [ctypes.c_int, _dp, _dp] + [ctypes.c_double] * 4 + [_dp]
         L.csp_oracle_alt_global_smooth.restype = ctypes.c_int
         L.csp_oracle_alt_global_smooth.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp]
+        L.csp_oracle_alt_optimize_banded.restype = ctypes.c_int
+        L.csp_oracle_alt_optimize_banded.argtypes = [ctypes.c_int, _dp, _dp] + [ctypes.c_double] * 4 + [_dp]
+        L.csp_oracle_alt_global_smooth_banded.restype = ctypes.c_int
+        L.csp_oracle_alt_global_smooth_banded.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_double, _dp]
         _lib = L
     return _lib
 
@@ -173,22 +177,24 @@ def enu_to_wgs84(enu, ref):
     return out
 
 
-def alt_optimize(xyz, elev, lambda_smooth=1.0, lambda_follow=0.0, safe_distance=50.0, max_climb_rate=2.0):
-    """optimizeHeights (uavPathPlanning.cpp:1575-1713); elev NaN = no terrain sample."""
+def alt_optimize(xyz, elev, lambda_smooth=1.0, lambda_follow=0.0, safe_distance=50.0, max_climb_rate=2.0, banded=False):
+    """optimizeHeights (uavPathPlanning.cpp:1575-1713); elev NaN = no terrain sample.  banded: the O(n) banded Cholesky on the
+    same equations (the one-core CPU time for ONE long problem)."""
     xyz, elev = _c(xyz).reshape(-1, 3), _c(elev)
     out = np.zeros(xyz.shape[0])
-    rc = lib().csp_oracle_alt_optimize(xyz.shape[0], _p(xyz), _p(elev), lambda_smooth, lambda_follow, safe_distance,
-                                       max_climb_rate, _p(out))
+    fn = lib().csp_oracle_alt_optimize_banded if banded else lib().csp_oracle_alt_optimize
+    rc = fn(xyz.shape[0], _p(xyz), _p(elev), lambda_smooth, lambda_follow, safe_distance, max_climb_rate, _p(out))
     if rc:
         raise ValueError("alt_optimize failed")
     return out
 
 
-def alt_global_smooth(input_z, xyz, lambda_smooth=1.0, max_climb_rate=2.0):
+def alt_global_smooth(input_z, xyz, lambda_smooth=1.0, max_climb_rate=2.0, banded=False):
     """optimizeHeightsGlobalSmooth (uavPathPlanning.cpp:1715-1827).  Returns (z, number of solves)."""
     input_z, xyz = _c(input_z), _c(xyz).reshape(-1, 3)
     out = np.zeros(xyz.shape[0])
-    n = lib().csp_oracle_alt_global_smooth(xyz.shape[0], _p(input_z), _p(xyz), lambda_smooth, max_climb_rate, _p(out))
+    fn = lib().csp_oracle_alt_global_smooth_banded if banded else lib().csp_oracle_alt_global_smooth
+    n = fn(xyz.shape[0], _p(input_z), _p(xyz), lambda_smooth, max_climb_rate, _p(out))
     if n < 0:
         raise ValueError("alt_global_smooth failed")
     return out, n

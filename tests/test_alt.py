@@ -134,3 +134,51 @@ def test_hip_lane_and_wave_kernels_agree(csp):
     assert np.array_equal(z_wave, z_lane[sel])
     assert np.array_equal(g_wave, g_lane[sel])
     assert np.array_equal(s_wave, s_lane[pick])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 300])
+def test_banded_oracle_matches_dense_oracle(n):
+    """The O(n) banded Cholesky of oracle/alt_oracle.c (the one-core CPU time of bench.py's single_altitude record) fills its
+    three bands by the same triplet rules as the dense matrix: same solutions to rounding, same number of active-set solves."""
+    rng = np.random.default_rng(40 + n)
+    xyz, elev = _problem(rng, n)
+    for lf in (0.0, 0.5):
+        a = oracle.alt_optimize(xyz, elev, 1.0, lf, 50.0, 2.0)
+        b = oracle.alt_optimize(xyz, elev, 1.0, lf, 50.0, 2.0, banded=True)
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a)))
+    (za, na), (zb, nb) = oracle.alt_global_smooth(xyz[:, 2], xyz, 1.0, 2.0), oracle.alt_global_smooth(xyz[:, 2], xyz, 1.0, 2.0, banded=True)
+    assert na == nb and np.max(np.abs(za - zb)) <= 1e-9 * max(1.0, np.max(np.abs(za)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 777, 2000, 2900, 3001, 20000])
+def test_hip_cyclic_reduction_for_one_long_problem(csp, n):
+    """A single long problem (the reference's own call pattern, uavPathPlanning.cpp:1670-1676, :1796-1799) runs block cyclic
+    reduction, one 1024-thread workgroup, block rows in LDS up to ~2900 samples and in the workspace beyond: against the CPU
+    oracle (dense Cholesky up to 777 samples, the banded one beyond) at 1e-8 relative, host- and device-memory forms, and a few
+    problems of different lengths in one call."""
+    import torch
+    rng = np.random.default_rng(50 + n)
+    xyz, elev = _problem(rng, n)
+    off = np.array([0, n], dtype=np.int64)
+    banded = n > 777
+    for lf in (0.0, 0.5):
+        ref = oracle.alt_optimize(xyz, elev, 1.0, lf, 50.0, 2.0, banded=banded)
+        got = csp.alt_optimize_heights_batch(xyz, elev, off, 1.0, lf, 50.0, 2.0)
+        assert np.max(np.abs(got - ref)) <= 1e-8 * np.max(np.abs(ref)), (n, lf)
+    zref, nref = oracle.alt_global_smooth(xyz[:, 2], xyz, 1.0, 2.0, banded=banded)
+    z, solves = csp.alt_global_smooth_batch(xyz[:, 2].copy(), xyz, off, 1.0, 2.0)
+    assert int(solves[0]) == nref
+    assert np.max(np.abs(z - zref)) <= 1e-8 * np.max(np.abs(zref))
+    # three problems of different lengths, device memory
+    lens = [n, 600, n // 2 + 300]
+    ps = [_problem(rng, m) for m in lens]
+    xyz3, elev3 = np.concatenate([p[0] for p in ps]), np.concatenate([p[1] for p in ps])
+    off3 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    d = [torch.from_numpy(x).cuda() for x in (xyz3, elev3, off3)]
+    got3 = csp.alt_optimize_heights_batch(d[0], d[1], d[2], 1.0, 0.5, 50.0, 2.0)
+    torch.cuda.synchronize()
+    got3 = got3.cpu().numpy()
+    for k, (pxyz, pelev) in enumerate(ps):
+        ref = oracle.alt_optimize(pxyz, pelev, 1.0, 0.5, 50.0, 2.0, banded=True)
+        assert np.max(np.abs(got3[off3[k]:off3[k + 1]] - ref)) <= 1e-8 * np.max(np.abs(ref)), (n, k)
