@@ -867,9 +867,13 @@ int plan_device(const csp_minsnap_desc *desc, const Shape &s, const void *waypoi
     // the pre-solve does not depend on vel_zero_weight: the first pass stores its t* indices, the others reuse them
     int *tau_buf = use_fixed(&g, gs) ? (int *)base : nullptr;
     if (phase != 2) {
-        if ((e = csp::launch_time_alloc_init(ta, s.f32, vw, iters, done, pending, desc->vel_zero_weight, st)) != hipSuccess)
+        // per-trajectory starting weights: the init kernel leaves vw alone (vel_zero_weight_out may BE the caller's weight
+        // array -- an in-place update -- and must not be overwritten with the scalar first), then they are copied in
+        // unless they are already there
+        const bool per = desc->vel_zero_weight_per_traj != nullptr;
+        if ((e = csp::launch_time_alloc_init(ta, s.f32, per ? nullptr : vw, iters, done, pending, desc->vel_zero_weight, st)) != hipSuccess)
             return hip_fail(e, "time_alloc launch");
-        if (desc->vel_zero_weight_per_traj)
+        if (per && vw != desc->vel_zero_weight_per_traj)
             CSP_HIP(hipMemcpyAsync(vw, desc->vel_zero_weight_per_traj, (size_t)s.B * 8, hipMemcpyDeviceToDevice, st));
     }
     const bool count = sync_early_exit || phase != 0;

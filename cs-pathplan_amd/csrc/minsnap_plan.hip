@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256) resolve_init_kernel(double *vw, int32_t *
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && pending) *pending = 0;
     if (b >= B) return;
-    vw[b] = vw0;
+    if (vw) vw[b] = vw0;
     iters[b] = 0;
     done[b] = 0;
 }

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) time_alloc_init_kernel(TimeAllocArgs a, i
                                                               int32_t *done, int32_t *pending, double vw0) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0 && pending) *pending = 0;
-    if (g < a.B) { vw[g] = vw0; iters[g] = 0; done[g] = 0; }
+    if (g < a.B) { if (vw) vw[g] = vw0; iters[g] = 0; done[g] = 0; }   // vw null: the caller copies per-trajectory weights in
     if (g >= total_seg) return;
     const int64_t b = g / a.S;
     const R *p = (const R *)a.wp + (g + b) * 3;

@@ -77,9 +77,12 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
 
 /* per-trajectory status bits written to `status` */
 #define CSP_TRAJ_OK 0
-#define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently);
-                                  the path-penalty kernels test the highest-power and constant coefficient of
-                                  every record, which every input and unknown of the segment enters         */
+#define CSP_TRAJ_NONFINITE 1   /* a coefficient is inf/NaN (the reference would return it silently).  The register-resident
+                                  kernels (uniform S <= 16, with or without the path penalty) test the highest-power and
+                                  the constant coefficient of every record -- every input and unknown of the segment
+                                  enters the former, the latter is the start waypoint --, so an inf/NaN that ARISES in a
+                                  middle coefficient alone (finite inputs of magnitude >~ 1e300) is not flagged there; the
+                                  chunked, span and generic kernels test every stored coefficient                       */
 #define CSP_TRAJ_NOT_SPD 2     /* a pivot of the free-derivative Hessian R_PP was <= 0              */
 #define CSP_TRAJ_SKIPPED 4     /* csp_minsnap_solve_mixed only: the trajectory was NOT solved (its order is outside 2..5
                                   or its segment count outside 1..256); its coefficient block is left untouched (zero-filled with CSP_MEM_HOST) */
@@ -195,7 +198,9 @@ int csp_minsnap_time_alloc_batch(const csp_minsnap_desc *desc, const void *waypo
  *   times      : out, [B][S] (same layout rules as the solve)
  *   coeffs     : out
  *   max_dev    : out, optional [B] f64 (final deviation metric)
- *   vel_zero_weight_out : optional [B] f64, the weight the final solve used
+ *   vel_zero_weight_out : optional [B] f64, the weight the final solve used.  max_dev, vel_zero_weight_out and
+ *                iterations are LIVE LOOP STATE during the call (the passes read and update them in place); with
+ *                CSP_MEM_DEVICE vel_zero_weight_out may alias desc->vel_zero_weight_per_traj (weights updated in place)
  *   iterations : optional [B] i32, number of weight increases (reference `iter`)
  *   workspace  : >= csp_minsnap_plan_workspace_bytes(desc) bytes (device); NULL/0 with CSP_MEM_HOST */
 int csp_minsnap_plan_batch(const csp_minsnap_desc *desc, const void *waypoints, double v_avg, double min_time_s,
@@ -245,6 +250,9 @@ const char *csp_minsnap_kernel_name(const csp_minsnap_desc *desc);
 /* Number of visible HIP devices whose architecture is gfx950 (0 => every solve call fails). */
 int csp_minsnap_device_count(void);
 
+/* Process-lifetime notes: the library keeps helper threads (staging copies), cached arenas, streams and RCCL communicators
+ * alive once used -- do not dlclose() it or fork() after the first call; HIP device ordinals up to 63 are supported.
+ * An idle arena keeps at most 512 MB of device memory (CSP_ARENA_KEEP_MB), larger ones are freed when the call returns. */
 /* CSP_MEM_HOST calls stage through per-device arenas (one device allocation + 16 MB of page-locked memory each) that are
  * cached between calls, so that the reference's call pattern -- one flight per call, uavPathPlanning.cpp:4423/:4461 -- does
  * not pay hipMalloc/hipFree every time.  This frees the arenas no call is using (optional; e.g. before a long idle phase). */
