@@ -157,6 +157,21 @@ def generate_trajectory(path, order=3, path_weight=0.0, vel_zero_weight=0.0, v_a
                                 "max_climb_rate": stats[3], "min_turn_radius": stats[4]}
 
 
+def sample(coeff, times, sample_distance, cap=None):
+    """The sampling loop of GenerateTrajectoryMatrix (minimum_snap.cpp:97-161) on GIVEN coefficients [S,3,2o] and times [S]
+    (pow()-based evaluation like the reference).  Returns the kept samples [n,3]."""
+    coeff, times = _c(coeff), _c(times)
+    S, m = times.shape[0], coeff.shape[-1]
+    if cap is None:
+        cap = int(np.sum(np.ceil(times / np.minimum(0.1, times / 10.0)))) + S + 4
+    out = np.zeros((cap, 3))
+    L = lib()
+    L.csp_oracle_sample.restype = ctypes.c_long
+    L.csp_oracle_sample.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp, ctypes.c_long]
+    n = L.csp_oracle_sample(S, m // 2, _p(coeff.reshape(-1)), _p(times), float(sample_distance), _p(out), cap)
+    return out[:min(n, cap)]
+
+
 def max_threads():
     return int(lib().csp_oracle_max_threads())
 

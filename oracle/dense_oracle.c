@@ -386,33 +386,10 @@ static void eval_poly(const double *coeff, int m, int seg, double t, double out[
     }
 }
 
-/* GenerateTrajectoryMatrix (:22-206): time allocation, re-solve loop, fixed-distance thinning.
- * cfg = {order, path_weight, vel_zero_weight, V_avg, min_time_s, sample_distance};
- * bc rows v0, v1, a0, a1.  Writes at most cap samples; returns the sample count (or -1 on the
- * reference's bad-shape path, :54-57).  stats = {final vel_zero_weight, iterations, max_dev,
- * max climb rate, min turn radius}. */
-long csp_oracle_generate_trajectory(int W, const double *path, int order, double path_weight,
-                                    double vel_zero_weight, double v_avg, double min_time_s,
-                                    double sample_distance, const double *bc, double *samples,
-                                    long cap, double *coeff_out, double *time_out, double *stats) {
-    if (W < 2) return -1;
-    const int S = W - 1, m = 2 * order;
-    double *T = (double *)malloc(sizeof(double) * (size_t)S);
-    double *coeff = (double *)malloc(sizeof(double) * (size_t)S * 3 * m);
-    csp_oracle_time_alloc(W, path, v_avg, min_time_s, T);
-    double vel[6] = {bc[0], bc[1], bc[2], bc[3], bc[4], bc[5]};
-    double acc[6] = {bc[6], bc[7], bc[8], bc[9], bc[10], bc[11]};
-    double max_dev = 0.0;
-    int iter = 0;
-    for (;;) {
-        if (csp_oracle_solve(order, S, path, vel, acc, T, path_weight, vel_zero_weight, coeff, &max_dev)) {
-            free(T); free(coeff); return -1;
-        }
-        if (max_dev > 0.2 && iter < 10) {
-            vel_zero_weight = (vel_zero_weight < 1e-6) ? 0.01 : vel_zero_weight * 2.0;
-            ++iter;
-        } else break;
-    }
+/* The sampling loop of GenerateTrajectoryMatrix (:97-161) on GIVEN coefficients: candidates at dt = min(0.1, T/10), evaluated
+ * term by term with pow() like the reference's eval lambda (:104-117), a candidate kept when its distance to the previously
+ * kept one is >= sample_distance (:142-150), the end point appended unless it repeats the last sample (:157-160). */
+static long sample_polynomials(int S, int m, const double *coeff, const double *T, double sample_distance, double *samples, long cap) {
     long n = 0;
     double prev[3] = {0, 0, 0}, cur[3], last[3] = {0, 0, 0};
     for (int seg = 0; seg < S; ++seg) {
@@ -442,6 +419,43 @@ long csp_oracle_generate_trajectory(int W, const double *path, int order, double
             }
         }
     }
+    return n;
+}
+
+/* The same loop as an entry point of its own (round 3): lets a test feed the oracle's pow()-based evaluation and the HIP
+ * sampler's power ladder THE SAME coefficients, so that what differs is the evaluation alone (the 1-ulp band of the keep test). */
+long csp_oracle_sample(int S, int order, const double *coeff, const double *times, double sample_distance, double *samples, long cap) {
+    return sample_polynomials(S, 2 * order, coeff, times, sample_distance, samples, cap);
+}
+
+/* GenerateTrajectoryMatrix (:22-206): time allocation, re-solve loop, fixed-distance thinning.
+ * cfg = {order, path_weight, vel_zero_weight, V_avg, min_time_s, sample_distance};
+ * bc rows v0, v1, a0, a1.  Writes at most cap samples; returns the sample count (or -1 on the
+ * reference's bad-shape path, :54-57).  stats = {final vel_zero_weight, iterations, max_dev,
+ * max climb rate, min turn radius}. */
+long csp_oracle_generate_trajectory(int W, const double *path, int order, double path_weight,
+                                    double vel_zero_weight, double v_avg, double min_time_s,
+                                    double sample_distance, const double *bc, double *samples,
+                                    long cap, double *coeff_out, double *time_out, double *stats) {
+    if (W < 2) return -1;
+    const int S = W - 1, m = 2 * order;
+    double *T = (double *)malloc(sizeof(double) * (size_t)S);
+    double *coeff = (double *)malloc(sizeof(double) * (size_t)S * 3 * m);
+    csp_oracle_time_alloc(W, path, v_avg, min_time_s, T);
+    double vel[6] = {bc[0], bc[1], bc[2], bc[3], bc[4], bc[5]};
+    double acc[6] = {bc[6], bc[7], bc[8], bc[9], bc[10], bc[11]};
+    double max_dev = 0.0;
+    int iter = 0;
+    for (;;) {
+        if (csp_oracle_solve(order, S, path, vel, acc, T, path_weight, vel_zero_weight, coeff, &max_dev)) {
+            free(T); free(coeff); return -1;
+        }
+        if (max_dev > 0.2 && iter < 10) {
+            vel_zero_weight = (vel_zero_weight < 1e-6) ? 0.01 : vel_zero_weight * 2.0;
+            ++iter;
+        } else break;
+    }
+    long n = sample_polynomials(S, m, coeff, T, sample_distance, samples, cap);
     if (stats) {
         double max_climb = 0.0, min_r = 1.0e12;
         long lim = n < cap ? n : cap;

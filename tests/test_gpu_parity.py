@@ -60,14 +60,16 @@ def test_golden_penalties(csp):
         assert abs(r.max_dev[0] - c["max_dev"]) < 1e-7 * max(1.0, abs(c["max_dev"])), (c["name"], r.max_dev[0], c["max_dev"])
 
 
-def test_golden_readme_uav31(csp, oracle_mod):
-    """README waypoints (config C1).  cond(M) reaches 1e16..1e20 in the reference's raw-time dense
+@pytest.mark.parametrize("fname", ["F2_readme_uav31.json", "F2b_readme_uav31_merged.json"])
+def test_golden_readme_uav31(csp, oracle_mod, fname):
+    """README waypoints (config C1): the seven of readme.md:14-20 (F2, six segments) and the six getPlan really feeds after its
+    200 m merge (F2b, five segments; uavPathPlanning.cpp:2643-2664).  cond(M) reaches 1e16..1e20 in the reference's raw-time dense
     formulation, so the fp64 dense answer is itself only accurate to a few digits; the 80-bit
     long-double oracle is the yardstick.  The gate is the PER-POWER relative error (every coefficient
     power judged against its own magnitude: the t^7 coefficients are ~1e-14 of the constant term here,
     and the constant term is just the waypoint copied through, so the norm-wise figure of SURVEY.md 8d
     -- printed beside it -- is vacuous on this fixture)."""
-    for c in load_cases("F2_readme_uav31.json"):
+    for c in load_cases(fname):
         ld, _ = oracle_mod.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], c["path_weight"],
                                  c["vel_zero_weight"], long_double=True)
         S, m = c["segments"], 2 * c["order"]

@@ -12,7 +12,7 @@ from oracle import numpy_ref as nr
 from tests import synth
 from tests.conftest import load_cases
 
-ALL = ["F1_kat.json", "F2_readme_uav31.json", "F3_wellscaled.json", "F5_ragged.json", "F6_penalties.json"]
+ALL = ["F1_kat.json", "F2_readme_uav31.json", "F2b_readme_uav31_merged.json", "F3_wellscaled.json", "F5_ragged.json", "F6_penalties.json"]
 
 
 def _rel(a, b):
