@@ -356,11 +356,21 @@ class MixedResult:
         self.coeffs, self.coeff_offsets, self.status = coeffs, coeff_offsets, status
 
 
-def mixed_coeff_total(orders, seg_offsets):
-    """Elements of the tightly concatenated coefficient array of a mixed batch: sum_b 6 * order_b * S_b (host or device)."""
+def mixed_block_elements(orders, seg_offsets, f32):
+    """Elements of every trajectory's coefficient block in csp_minsnap_solve_mixed's layout: 6 * order * S rounded up to whole
+    16-byte pieces (fp32: a multiple of 4; fp64: no padding).  Host arrays or device tensors; returns the same kind."""
+    pad = 4 if f32 else 2
     if _is_torch(seg_offsets):
-        return int(((seg_offsets[1:] - seg_offsets[:-1]) * 6 * orders.to(seg_offsets.dtype)).sum().item())
-    return int(np.sum(np.diff(np.asarray(seg_offsets, dtype=np.int64)) * 6 * np.asarray(orders, dtype=np.int64)))
+        e = (seg_offsets[1:] - seg_offsets[:-1]) * 6 * orders.to(seg_offsets.dtype)
+        return (e + pad - 1) // pad * pad
+    e = np.diff(np.asarray(seg_offsets, dtype=np.int64)) * 6 * np.asarray(orders, dtype=np.int64)
+    return (e + pad - 1) // pad * pad
+
+
+def mixed_coeff_total(orders, seg_offsets, f32=False):
+    """Elements of the coefficient array of a mixed batch (host or device shapes)."""
+    e = mixed_block_elements(orders, seg_offsets, f32)
+    return int(e.sum().item()) if _is_torch(seg_offsets) else int(np.sum(e))
 
 
 class PreparedMixed:
@@ -381,7 +391,7 @@ class PreparedMixed:
         if max_segments is None:
             max_segments = int((self.off[1:] - self.off[:-1]).max().item()) if B else 1
         self.bc = (torch.zeros((1, 4, 3), dtype=tdt, device=self.dev) if bc is None else bc.to(tdt).contiguous().reshape(-1, 4, 3))
-        self.total = mixed_coeff_total(self.orders, self.off)
+        self.total = mixed_coeff_total(self.orders, self.off, dtype == DTYPE_F32)
         self.out = out if out is not None else torch.empty(max(self.total, 1), dtype=tdt, device=self.dev)
         self.coeff_offsets = torch.empty(B + 1, dtype=torch.int64, device=self.dev)
         self.status = torch.empty(B, dtype=torch.int32, device=self.dev) if want_status else None
@@ -427,7 +437,7 @@ def solve_mixed(orders, waypoints, times, seg_offsets, bc=None, vel_zero_weight=
     if max_segments is None:
         max_segments = int(np.max(np.diff(seg_offsets))) if B else 1
     bc = np.zeros((1, 4, 3), dtype=npdt) if bc is None else np.ascontiguousarray(bc, dtype=npdt).reshape(-1, 4, 3)
-    out = np.empty(max(mixed_coeff_total(orders, seg_offsets), 1), dtype=npdt)
+    out = np.empty(max(mixed_coeff_total(orders, seg_offsets, dtype == DTYPE_F32), 1), dtype=npdt)
     cof = np.empty(B + 1, dtype=np.int64)
     stt = np.empty(B, dtype=np.int32) if want_status else None
     vwp = np.ascontiguousarray(vel_zero_weight_per_traj, dtype=np.float64) if vel_zero_weight_per_traj is not None else None

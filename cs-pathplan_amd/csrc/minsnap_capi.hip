@@ -668,7 +668,7 @@ int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders,
     for (int64_t b = 0; b < B; ++b) {
         const int64_t n = desc->seg_offsets[b + 1] - desc->seg_offsets[b];
         if (n < 0 || n > desc->max_segments) return CSP_ERR_INVALID_ARG;
-        if (orders[b] >= 1) total_co += (size_t)n * 6 * (size_t)orders[b];
+        if (orders[b] >= 1 && n > 0) { const size_t e = (size_t)n * 6 * (size_t)orders[b], pad = f32 ? 4 : 2; total_co += (e + pad - 1) / pad * pad; }
     }
     csp::HostCall hc(current_device(), st);
     const size_t o_wp = hc.in(waypoints, (size_t)(total_seg + B) * 3 * elt), o_tm = hc.in(times, (size_t)total_seg * elt);

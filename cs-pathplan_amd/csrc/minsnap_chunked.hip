@@ -23,7 +23,7 @@ minsnap_chunked_kernel(GenericArgs a, int lpt_log2) {
     int S;
     if (a.seg_off) { seg0 = a.seg_off[bb]; S = (int)(a.seg_off[bb + 1] - seg0); }
     else { seg0 = bb * (int64_t)a.S; S = a.S; }
-    chunked_body<O, IO, STATUS, false>(a, lds, xch, lane, lpt_log2, traj_ok, bb, seg0, S, seg0 * (int64_t)(6 * O));
+    chunked_body<O, IO, STATUS, false>(a, lds, xch, lane, 1 << lpt_log2, lane & ((1 << lpt_log2) - 1), traj_ok, bb, seg0, S, seg0 * (int64_t)(6 * O));
 }
 
 template <int O> hipError_t launch_o(const GenericArgs &a, bool f32, int lpt_log2, hipStream_t st) {

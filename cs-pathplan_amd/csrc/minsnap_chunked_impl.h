@@ -41,43 +41,65 @@ constexpr int CMAX = 4;  // segments per chunk
 template <typename IO> __device__ __forceinline__ double ld(const IO *p) { return (double)*p; }
 
 // This lane's chunk: c segments starting at segment s0 of a trajectory whose first segment is seg0
-// (global, ragged prefix) and whose first waypoint is point seg0 + b.  REV loads it time-reversed.
+// (global, ragged prefix) and whose first waypoint is point seg0 + b.
+// The chunk's inputs are read ONCE, raw (storage type, forward order), and kept in registers (19 values: 19 VGPRs for fp32
+// storage, 38 for fp64): the three passes over the chunk (reversed Schur sweep, forward Schur sweep, solve) used to load them
+// three times, and at two waves per SIMD each of those load phases was an exposed memory round trip (round 3).
 // Inside an active lane every load is issued unconditionally (indices clamped into the chunk, the unused slots overwritten
 // by a select afterwards): with `(i < c) ? load : constant` hipcc put every load into a basic block of its own and
-// followed it with s_waitcnt vmcnt(0) -- 19 exposed memory round trips per call, three calls per lane, which was more
-// than half of a wave's life.
-template <typename IO, bool REV>
-__device__ __forceinline__ void load_chunk(const IO *wp, const IO *tm, int64_t pt0, int64_t sg0, int c,
-                                           double (&T)[CMAX], double (&P)[CMAX + 1][3]) {
+// followed it with s_waitcnt vmcnt(0) -- 19 exposed memory round trips per call, which was more than half of a wave's life.
+template <typename IO> struct RawChunk {
     IO t[CMAX], p[CMAX + 1][3];
+};
+
+template <typename IO>
+__device__ __forceinline__ void load_raw(const IO *wp, const IO *tm, int64_t pt0, int64_t sg0, int c, RawChunk<IO> &r) {
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
-        t[i] = (IO)1;
+        r.t[i] = (IO)1;
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) p[i][ax] = (IO)0;
+        for (int ax = 0; ax < 3; ++ax) r.p[i][ax] = (IO)0;
     }
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) p[CMAX][ax] = (IO)0;
+    for (int ax = 0; ax < 3; ++ax) r.p[CMAX][ax] = (IO)0;
     if (c > 0) {   // ONE branch per call (idle lanes touch no memory), none per load
 #pragma unroll
-        for (int i = 0; i < CMAX; ++i) {
-            const int ii = i < c ? i : c - 1;
-            t[i] = tm[sg0 + (REV ? c - 1 - ii : ii)];
-        }
+        for (int i = 0; i < CMAX; ++i) r.t[i] = tm[sg0 + (i < c ? i : c - 1)];
 #pragma unroll
         for (int i = 0; i <= CMAX; ++i) {
-            const int ii = i <= c ? i : c;
-            const int64_t q = pt0 + (REV ? c - ii : ii);
+            const int64_t q = pt0 + (i <= c ? i : c);
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) p[i][ax] = wp[q * 3 + ax];
+            for (int ax = 0; ax < 3; ++ax) r.p[i][ax] = wp[q * 3 + ax];
         }
     }
+}
+
+// The chunk in local order from the raw registers; REV: time-reversed (segment i <- c-1-i, waypoint i <- c-i; selects on the
+// raw values, c differs between lanes).  Slots beyond the chunk read T = 1, P = 0.
+template <typename IO, bool REV>
+__device__ __forceinline__ void chunk_view(const RawChunk<IO> &r, int c, double (&T)[CMAX], double (&P)[CMAX + 1][3]) {
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) T[i] = (i < c) ? (double)t[i] : 1.0;
+    for (int i = 0; i < CMAX; ++i) {
+        IO v = r.t[i];
+        if (REV) {
+            v = r.t[0];
+#pragma unroll
+            for (int k = 1; k < CMAX; ++k) v = (c - 1 - i == k) ? r.t[k] : v;
+        }
+        T[i] = (i < c) ? (double)v : 1.0;
+    }
 #pragma unroll
     for (int i = 0; i <= CMAX; ++i)
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) P[i][ax] = (i <= c) ? (double)p[i][ax] : 0.0;
+        for (int ax = 0; ax < 3; ++ax) {
+            IO v = r.p[i][ax];
+            if (REV) {
+                v = r.p[0][ax];
+#pragma unroll
+                for (int k = 1; k <= CMAX; ++k) v = (c - i == k) ? r.p[k][ax] : v;
+            }
+            P[i][ax] = (i <= c) ? (double)v : 0.0;
+        }
 }
 
 // Step 1.  Eliminates the chunk's interior waypoints in local order with the START interface x_s as a
@@ -176,17 +198,17 @@ using iface::IfaceLds;
 using iface::store_axis;
 
 
-// The body of one wave: 64 >> lpt_log2 trajectories, lpt lanes each.  `lane`'s trajectory is `bb` (caller index: boundary
+// The body of one wave: 64 / lpt trajectories, lpt lanes each.  `lane`'s trajectory is `bb` (caller index: boundary
 // conditions, weights and status are indexed by it) of S segments starting at segment seg0 / waypoint seg0 + bb of the
 // concatenated inputs; its coefficients start at element coef0 of `coeffs`.  ALIGN8: the coefficient block is only
 // 8-byte aligned (fp32 storage in a mixed-order batch), so records leave in 8-byte pieces.
 template <int O, typename IO, bool STATUS, bool ALIGN8>
-__device__ __forceinline__ void chunked_body(const GenericArgs &a, double *lds, double *xch, int lane, int lpt_log2, bool traj_ok,
+__device__ __forceinline__ void chunked_body(const GenericArgs &a, double *lds, double *xch, int lane, int lpt, int j, bool traj_ok,
                                              int64_t bb, int64_t seg0, int S, int64_t coef0) {
     constexpr int N = O - 1, M = 2 * O;
     using IL = IfaceLds<O>;
-    const int lpt = 1 << lpt_log2;
-    const int j = lane & (lpt - 1);                                  // my chunk
+    // lpt consecutive lanes share the trajectory (a power of two in the one-order kernel, any 1..64 in the mixed-order one);
+    // j = my chunk = my position among them
     const int64_t b = bb;
     if (!traj_ok) S = 0;
     const int nch = S < lpt ? S : lpt;          // chunks in use (S >= 1 for a real trajectory)
@@ -200,11 +222,13 @@ __device__ __forceinline__ void chunked_body(const GenericArgs &a, double *lds, 
 
     bool spd = true;
     double T[CMAX], P[CMAX + 1][3];
+    RawChunk<IO> raw;
     // ---- step 1: the chunk's Schur complement onto its two interfaces ----
     double DR[N][N], rR[N][3];
     {
         double DL[N][N], rL[N][3], Et[N][N], unused[N][N];
-        load_chunk<IO, true>(wp, tm, pt0, sg0, c, T, P);
+        load_raw<IO>(wp, tm, pt0, sg0, c, raw);
+        chunk_view<IO, true>(raw, c, T, P);
         spd &= chunk_schur<O, false>(T, P, c, vw, DL, rL, unused);       // reversed frame: the START interface row
         if (active) {
             int e = 0;
@@ -217,7 +241,7 @@ __device__ __forceinline__ void chunked_body(const GenericArgs &a, double *lds, 
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) lds[(e++) * 64 + lane] = (r & 1) ? rL[r][ax] : -rL[r][ax];  // derivative r+1 is odd for even r
         }
-        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
+        chunk_view<IO, false>(raw, c, T, P);
         spd &= chunk_schur<O, true>(T, P, c, vw, DR, rR, Et);            // end row: DR x_R + Et x_L = rR
         if (active) {
 #pragma unroll
@@ -261,7 +285,7 @@ __device__ __forceinline__ void chunked_body(const GenericArgs &a, double *lds, 
     // ---- step 3: the chunk as a little trajectory with every derivative known at both ends ----
     double nanacc = 0.0;
     if (active) {
-        load_chunk<IO, false>(wp, tm, pt0, sg0, c, T, P);
+        chunk_view<IO, false>(raw, c, T, P);
         double W[N][N], z[N][3];
         double Wst[CMAX][N][N], zst[CMAX][N][3];   // slot k = local waypoint k (slot 0 unused)
 #pragma unroll

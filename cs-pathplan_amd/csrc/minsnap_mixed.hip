@@ -1,6 +1,6 @@
 // minsnap_mixed.hip -- mixed-ORDER ragged batches in one call (BASELINE config 5: per-trajectory segment count and
 // derivative order; csp_minsnap_solve_mixed, include/csp_minsnap.h).  Everything happens on the device and in the
-// caller's own order -- no gather, no un-permute:
+// caller's own order -- no gather, no un-permute (blocks 16-byte aligned: block_elems):
 //
 //   1. bucketing (three small kernels): every trajectory gets the key (order, length class) -- the length class is the
 //      number of lanes the workspace-free kernel gives a trajectory (minsnap_chunked_impl.h: 4 segments per lane, rounded
@@ -17,30 +17,41 @@
 #include "minsnap_chunked_impl.h"
 #include "minsnap_mixed.h"
 
+#include <cstdlib>
+
 namespace csp {
 namespace mixed {
 
-constexpr int NCLS = 7;          // lanes per trajectory 64, 32, .., 1 (class k <-> lpt_log2 = 6 - k): longest first
+constexpr int NCLS = 64;         // class k <-> 64 - k lanes per trajectory (one lane per chunk of <= 4 segments): longest first
 constexpr int NORD = 4;          // orders 2..5
 constexpr int ITEMS = 4;         // trajectories per thread of the bucketing kernels
 constexpr int BT = 256;          // threads per bucketing block
 
-__device__ __forceinline__ int lanes_log2(int S) {   // chunked_lanes_log2 on the device: 4 segments per lane
-    int l = 0;
-    while ((chunked::CMAX << l) < S) ++l;
-    return l;
+// lanes a trajectory of S segments gets: one per chunk of <= 4 segments.  (The one-order kernel rounds this up to a power
+// of two and gives a whole call the lanes of its longest trajectory; here the classes are exact, so a 33-segment trajectory
+// takes 9 lanes, not 16, seven of them share a wave, and the interface solve runs 7 steps, not 14.)
+__device__ __forceinline__ int lanes_of(int S) { return (S + chunked::CMAX - 1) / chunked::CMAX; }
+
+// Elements of a trajectory's coefficient block in the caller-order layout: 6 * order * S, rounded up to a whole number of
+// 16-byte pieces (fp32 storage: a multiple of 4 elements -- odd orders with an odd segment count carry 2 floats of padding),
+// so that every block starts 16-byte aligned and records leave in 16-byte stores (8-byte stores to 8-byte aligned blocks
+// doubled the write requests and cost the fp32 mixed batch a fifth of its time).
+__device__ __forceinline__ long long block_elems(int o, int64_t S, int pad_to) {
+    if (o < 1 || S <= 0) return 0;
+    const long long n = (long long)S * 6 * o;
+    return (n + pad_to - 1) / pad_to * pad_to;
 }
 
 // key = order index * NCLS + class, or -1 for a trajectory this path does not serve (order outside 2..5, S outside 1..256)
 __device__ __forceinline__ int key_of(int order, int64_t S) {
     if (order < 2 || order > 5 || S < 1 || S > chunked::CMAX * 64) return -1;
-    return (order - 2) * NCLS + (6 - lanes_log2((int)S));
+    return (order - 2) * NCLS + (64 - lanes_of((int)S));
 }
 
 // No global atomics anywhere in the bucketing: same-address device-scope atomics cost ~60 ns EACH on this part (measured:
 // a first version whose persistent waves pulled work units from one counter spent 1.2 ms on 20 k atomicAdds, whatever
 // the work), so blocks publish their histograms and the planning block turns them into per-block offsets.
-__global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, int32_t *hist_blk, int64_t *block_sum) {
+__global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, int32_t *hist_blk, int64_t *block_sum, int pad_to) {
     __shared__ int hist[NORD * NCLS];
     __shared__ long long wsum[BT / 64];
     const int tid = threadIdx.x;
@@ -56,7 +67,7 @@ __global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const 
             const int k = key_of(o, S);
             if (k >= 0) atomicAdd(&hist[k], 1);
             // the coefficient block exists in the caller's layout whether or not the trajectory is served
-            csz += (o >= 1 && S > 0) ? (long long)S * 6 * o : 0;
+            csz += block_elems(o, S, pad_to);
         }
     }
 #pragma unroll
@@ -104,7 +115,7 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
                 const int n = total[o * NCLS + k];
                 tab->bucket_start[o][k] = start;
                 tab->unit_start[o][k] = units;
-                const int per_wave = 64 >> (6 - k);                  // trajectories per 64-lane work unit
+                const int per_wave = 64 / (64 - k);                  // trajectories per 64-lane work unit
                 units += (n + per_wave - 1) / per_wave;
                 start += n;
             }
@@ -136,7 +147,7 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
 
 __global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, const MixedTable *tab,
                                                      const int32_t *blk_base, const int64_t *block_pre, int64_t *coef_off, int32_t *perm,
-                                                     int32_t *status) {
+                                                     int32_t *status, int pad_to) {
     __shared__ int hist[NORD * NCLS], base[NORD * NCLS];
     __shared__ long long wtot[BT / 64];
     const int tid = threadIdx.x;
@@ -156,7 +167,7 @@ __global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, cons
             const int o = orders[i];
             const int64_t S = seg_off[i + 1] - seg_off[i];
             key[it] = key_of(o, S);
-            csz[it] = (o >= 1 && S > 0) ? (long long)S * 6 * o : 0;
+            csz[it] = block_elems(o, S, pad_to);
             if (key[it] >= 0) rank[it] = atomicAdd(&hist[key[it]], 1);
             if (status) status[i] = key[it] >= 0 ? 0 : CSP_TRAJ_SKIPPED_BIT;   // the solve kernels OR their bits in
         }
@@ -197,25 +208,33 @@ minsnap_chunked_mixed_kernel(GenericArgs a, const int32_t *perm, const int64_t *
     using IL = iface::IfaceLds<O>;
     __shared__ double lds[IL::ENTRIES * 64];
     __shared__ double xch[3 * (O - 1) * 64];
+    __shared__ int s_ustart[NCLS + 1], s_bstart[NCLS + 1];
     const int lane = threadIdx.x;
     constexpr int oi = O - 2;
-    int ustart[NCLS + 1], bstart[NCLS + 1];
-#pragma unroll
-    for (int k = 0; k <= NCLS; ++k) { ustart[k] = tab->unit_start[oi][k]; bstart[k] = tab->bucket_start[oi][k]; }
-    const int total = ustart[NCLS];
+    s_ustart[lane] = tab->unit_start[oi][lane];
+    s_bstart[lane] = tab->bucket_start[oi][lane];
+    if (lane == 0) { s_ustart[NCLS] = tab->unit_start[oi][NCLS]; s_bstart[NCLS] = tab->bucket_start[oi][NCLS]; }
+    __syncthreads();
+    const int total = s_ustart[NCLS];
     for (int u = blockIdx.x; u < total; u += gridDim.x) {
-        int k = 0, u0 = ustart[0], lo = bstart[0], hi = bstart[1];
+        // the class of unit u: the last k with unit_start[k] <= u (binary search, wave-uniform LDS broadcasts)
+        int k = 0;
 #pragma unroll
-        for (int q = 1; q < NCLS; ++q)
-            if (u >= ustart[q]) { k = q; u0 = ustart[q]; lo = bstart[q]; hi = bstart[q + 1]; }   // wave-uniform selects
-        const int lpt_log2 = 6 - k;
-        const int idx = lo + (((u - u0) * 64 + lane) >> lpt_log2);
-        const bool traj_ok = idx < hi;
+        for (int step = NCLS / 2; step >= 1; step >>= 1)
+            if (s_ustart[k + step] <= u) k += step;
+        const int lpt = 64 - k;                      // lanes per trajectory
+        const int tpw = 64 / lpt;                    // trajectories per wave
+        const int lo = s_bstart[k], hi = s_bstart[k + 1];
+        // lane -> (trajectory of the wave, chunk): exact for lane < 64 (multiply-shift reciprocal)
+        const int t_in = (lane * ((65536 + lpt - 1) / lpt)) >> 16;
+        const int j = lane - t_in * lpt;
+        const int idx = lo + (u - s_ustart[k]) * tpw + t_in;
+        const bool traj_ok = t_in < tpw && idx < hi;
         const int64_t bb = perm[traj_ok ? idx : hi - 1];
         const int64_t seg0 = a.seg_off[bb];
         const int S = (int)(a.seg_off[bb + 1] - seg0);
-        chunked::chunked_body<O, IO, STATUS, true>(a, lds, xch, lane, lpt_log2, traj_ok, bb, seg0, S, coef_off[bb]);
-        __syncthreads();   // the LDS images are reused by the next unit
+        chunked::chunked_body<O, IO, STATUS, false>(a, lds, xch, lane, lpt, j, traj_ok, bb, seg0, S, coef_off[bb]);
+        fixedk::lds_barrier();   // the LDS images are reused by the next unit (LDS-only: the unit's stores stay in flight)
     }
 }
 
@@ -237,7 +256,7 @@ template <int O> hipError_t launch_order(const GenericArgs &a, bool f32, const i
 size_t mixed_workspace_bytes(int64_t B) {
     const int64_t nblk = (B + mixed::BT * mixed::ITEMS - 1) / (mixed::BT * mixed::ITEMS);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    return up(sizeof(MixedTable)) + up((size_t)(nblk + 1) * 8) + up((size_t)nblk * 28 * 4) + up((size_t)(B + 1) * 8) + up((size_t)B * 4);
+    return up(sizeof(MixedTable)) + up((size_t)(nblk + 1) * 8) + up((size_t)nblk * 4 * mixed::NCLS * 4) + up((size_t)(B + 1) * 8) + up((size_t)B * 4);
 }
 
 // Forked streams of one device for the per-order launches (created once per device and thread, never destroyed: the
@@ -274,15 +293,16 @@ hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, v
     char *w = (char *)workspace;
     MixedTable *tab = (MixedTable *)w;                 w += up(sizeof(MixedTable));
     int64_t *block_sum = (int64_t *)w;                 w += up((size_t)(nblk + 1) * 8);
-    int32_t *hist_blk = (int32_t *)w;                  w += up((size_t)nblk * 28 * 4);
+    int32_t *hist_blk = (int32_t *)w;                  w += up((size_t)nblk * NORD * NCLS * 4);
     int64_t *coef_ws = (int64_t *)w;                   w += up((size_t)(B + 1) * 8);
     int32_t *perm = (int32_t *)w;
     int64_t *coef_off = coef_off_out ? coef_off_out : coef_ws;
     hipError_t e;
     // no memsets: the three kernels write every word they or the solve read (status included)
-    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, hist_blk, block_sum);
+    const int pad_to = f32 ? 4 : 2;
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, hist_blk, block_sum, pad_to);
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(BT), 0, st, tab, hist_blk, block_sum, nblk, coef_off, B);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, tab, hist_blk, block_sum, coef_off, perm, a.status);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, tab, hist_blk, block_sum, coef_off, perm, a.status, pad_to);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // persistent grids: what one order can keep resident (CUs x SIMDs x waves per SIMD), capped by the work there can be
     static int cus = 0;
@@ -294,7 +314,10 @@ hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, v
     }
     // a unit holds at least one trajectory, so B units bound every order's list
     auto waves_for = [&](int per_simd) { const int64_t cap = (int64_t)cus * 4 * per_simd; return (int)(B < cap ? B : cap); };
-    Fork *f = fork_for_device();
+    // CSP_MIXED_FORK=1: the orders' launches on forked streams (concurrent, but the event fork / join between hardware
+    // queues costs tens of microseconds); default: one after the other on the caller's stream
+    static const bool fork = [] { const char *e = std::getenv("CSP_MIXED_FORK"); return e && e[0] == '1'; }();
+    Fork *f = fork ? fork_for_device() : nullptr;
     if (!f) {   // no side streams: the four orders one after the other on the caller's stream
         if ((e = launch_order<5>(a, f32, perm, coef_off, tab, waves_for(1), st)) != hipSuccess) return e;
         if ((e = launch_order<4>(a, f32, perm, coef_off, tab, waves_for(2), st)) != hipSuccess) return e;

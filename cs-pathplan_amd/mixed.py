@@ -30,7 +30,7 @@ def solve_mixed(trajs, dtype=np.float32, device=None):
     else:
         r = csp.solve_mixed(orders, wp, tm, off, want_status=True)
         co, cof, st = r.coeffs, r.coeff_offsets, r.status
-    out = [co[cof[i]:cof[i + 1]].reshape(len(t[2]), 3, 2 * t[0]) for i, t in enumerate(trajs)]
+    out = [co[cof[i]:cof[i] + 6 * t[0] * len(t[2])].reshape(len(t[2]), 3, 2 * t[0]) for i, t in enumerate(trajs)]
     return out, st
 
 
@@ -49,7 +49,8 @@ class MixedBatch:
         self.shapes = [(len(t[2]), int(t[0])) for t in trajs]
         self.prep = csp.PreparedMixed(torch.from_numpy(orders).to(device), torch.from_numpy(wp).to(device), torch.from_numpy(tm).to(device),
                                       torch.from_numpy(off).to(device), max_segments=int(np.max(np.diff(off))))
-        self.offsets = np.concatenate([[0], np.cumsum([6 * o * n for n, o in self.shapes])]).astype(np.int64)
+        pad = 4 if dtype == torch.float32 else 2
+        self.offsets = np.concatenate([[0], np.cumsum([(6 * o * n + pad - 1) // pad * pad for n, o in self.shapes])]).astype(np.int64)
         self.algorithmic_bytes = int(sum(width * (3 * (n + 1) + n) + width * 3 * n * 2 * o for n, o in self.shapes))
         self.launches = 1
         self.kernels = ["mixed (device-side bucketing + one persistent chunked launch per order)"]
@@ -59,4 +60,4 @@ class MixedBatch:
 
     def coeffs(self, i):
         n, o = self.shapes[i]
-        return self.prep.out[self.offsets[i]:self.offsets[i + 1]].reshape(n, 3, 2 * o)
+        return self.prep.out[self.offsets[i]:self.offsets[i] + 6 * o * n].reshape(n, 3, 2 * o)

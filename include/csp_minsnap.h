@@ -171,9 +171,12 @@ int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *
  *                 vel_zero_weight(_per_traj), mem_space, device_id as for csp_minsnap_solve_batch; desc->order and
  *                 num_segments are ignored; path_weight must be 0 and CSP_FLAG_F32_ARITH is not offered (CSP_ERR_UNSUPPORTED)
  *   orders      : [B] int32, derivative order of every trajectory, 2..5 (same memory space as the data)
- *   coeffs      : trajectory b's block [S_b][3][2*order_b] starts at element coeff_offsets[b] = sum_{k<b} 6*order_k*S_k
- *                 (tightly concatenated in caller order; the caller sizes it, e.g. from its own host copy of the shapes)
- *   coeff_offsets_out : optional [B+1] int64, the offsets above (computed on the device)
+ *   coeffs      : trajectory b's block [S_b][3][2*order_b] starts at element coeff_offsets[b] = sum_{k<b} E_k, concatenated in
+ *                 caller order, where E_k = 6*order_k*S_k rounded up to a whole number of 16-byte pieces (fp32 storage: a
+ *                 multiple of 4 elements, i.e. 2 floats of padding after a block of odd order AND odd segment count; fp64:
+ *                 no padding ever) -- every block starts 16-byte aligned.  The caller sizes the array (sum_b E_b <= the
+ *                 tight sum + 2*B elements), e.g. from its own host copy of the shapes
+ *   coeff_offsets_out : optional [B+1] int64, the offsets above (computed on the device); [B] = the total
  *   status      : optional [B] int32 CSP_TRAJ_* bits; trajectories outside the served range get CSP_TRAJ_SKIPPED
  *   workspace   : >= csp_minsnap_mixed_workspace_bytes(desc) bytes of device memory (CSP_MEM_DEVICE); NULL/0 with CSP_MEM_HOST
  * Per trajectory the arithmetic is csp_minsnap_solve_batch's workspace-free kernel for that order and length class.

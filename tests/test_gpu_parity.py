@@ -305,8 +305,8 @@ def _per_class_reference(csp, trajs, dtype, f32_arith=False):
 
 def test_f32_storage_mixed_batch_c5(csp, oracle_mod):
     """BASELINE config C5 shape: S ~ U{4..64}, order ~ U{3,4,5}, fp32 storage, through csp_minsnap_solve_mixed (host-memory
-    form here): device-side bucketing, coefficients in the caller's order.  Bit-equal with one ragged solve_batch call per
-    (order, length class).  The reference defines no fp32 behaviour (parity unpinned, builder-defined gates): with the
+    form here): device-side bucketing, coefficients in the caller's order.  Agrees with one ragged solve_batch call per
+    (order, length class) to the final fp32 rounding.  The reference defines no fp32 behaviour (parity unpinned, builder-defined gates): with the
     default fp64 arithmetic the only loss is the final rounding to fp32 (gate 1e-6 relative to the 80-bit oracle run on the
     same fp32-rounded inputs); pure fp32 arithmetic (CSP_FLAG_F32_ARITH, solve_batch only -- the mixed entry does not offer
     it) is gated at 1e-3 / 5e-3 / 1e-1 for order 3 / 4 / 5 and its measured error is printed."""
@@ -317,9 +317,13 @@ def test_f32_storage_mixed_batch_c5(csp, oracle_mod):
     trajs = synth.make_ragged(240)
     got, status = mixed.solve_mixed(trajs, dtype=np.float32)
     assert not status.any()
+    # against one ragged solve_batch call per (order, power-of-two length class): the same kernel body, but the mixed entry gives
+    # a trajectory exactly ceil(S / 4) lanes where the one-order call rounds up to a power of two -- a different chunking of
+    # the same elimination, so the fp32 results agree to the final rounding, not bit for bit
     ref_calls = _per_class_reference(csp, trajs, np.float32)
     for i, (c, r) in enumerate(zip(got, ref_calls)):
-        assert c.dtype == np.float32 and np.array_equal(c, r), i
+        assert c.dtype == np.float32
+        synth.parity_gate(c, r, 1e-6, ("mixed entry vs per-class calls, fp32 storage", i))
     got32 = _per_class_reference(csp, trajs, np.float32, f32_arith=True)
     worst = {3: 0.0, 4: 0.0, 5: 0.0}
     worst32 = {3: 0.0, 4: 0.0, 5: 0.0}

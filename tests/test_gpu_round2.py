@@ -384,10 +384,16 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
     prep.run()                        # a second call on the same workspace (counters and cursors are reset by the call)
     torch.cuda.synchronize()
     assert int(prep.status.abs().max()) == 0
-    host_off = np.concatenate([[0], np.cumsum(np.diff(off_h) * 6 * orders.astype(np.int64))])
+    blk = csp.mixed_block_elements(orders, off_h, True)        # 6 * order * S rounded up to whole 16-byte pieces (fp32: multiples of 4)
+    tight = np.diff(off_h) * 6 * orders.astype(np.int64)
+    assert ((blk - tight) >= 0).all() and ((blk - tight) <= 2).all() and (blk % 4 == 0).all()
+    host_off = np.concatenate([[0], np.cumsum(blk)])
     assert np.array_equal(prep.coeff_offsets.cpu().numpy(), host_off)
     out = prep.out
-    assert bool(torch.isfinite(out).all())
+    pad_mask = torch.ones_like(out, dtype=torch.bool)          # every element but the padding must have been written
+    pad_idx = np.concatenate([np.arange(host_off[i] + tight[i], host_off[i + 1]) for i in np.nonzero(blk != tight)[0]])
+    pad_mask[torch.from_numpy(pad_idx).to(dev)] = False
+    assert bool(torch.isfinite(out[pad_mask]).all()) and bool(torch.isnan(out[~pad_mask]).all())
     lens = d_off[1:] - d_off[:-1]
     seg_traj = torch.repeat_interleave(torch.arange(B, device=dev), lens)                 # trajectory of each segment
     seg_idx = torch.arange(int(d_off[-1]), device=dev)
@@ -431,19 +437,21 @@ def test_c5_full_size_mixed_batch(csp, oracle_mod):
         o, w, t = trajs[i]
         w32, t32 = w.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)
         ref, _ = oracle_mod.solve(o, w32, z, z, t32, long_double=True)
-        got = out_h[host_off[i]:host_off[i + 1]].astype(np.float64).reshape(ref.shape)
+        got = out_h[host_off[i]:host_off[i] + tight[i]].astype(np.float64).reshape(ref.shape)
         worst[o] = max(worst[o], float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
     print("C5 full size, 192 of 65536 trajectories vs the 80-bit oracle (norm-wise, fp32 storage):", worst)
     assert all(v < 1e-6 for v in worst.values()), worst
     # MixedBatch (bench.py's object) is the same call
     mb = mixed.MixedBatch(csp, trajs[:5000], dev, dtype=torch.float32)
+    mb.prep.out.zero_()               # the 2-float paddings after odd-order, odd-length blocks are never written
     mb.run()
     torch.cuda.synchronize()
     small = csp.PreparedMixed(d_or[:5000], d_wp[:int(off_h[5000]) + 5000], d_tm[:int(off_h[5000])], d_off[:5001])
+    small.out.zero_()
     small.run()
     torch.cuda.synchronize()
     assert torch.equal(mb.prep.out, small.out)
-    assert torch.equal(mb.coeffs(4999), small.out[int(host_off[4999]):int(host_off[5000])].reshape(len(trajs[4999][2]), 3, 2 * trajs[4999][0]))
+    assert torch.equal(mb.coeffs(4999), small.out[int(host_off[4999]):int(host_off[4999] + tight[4999])].reshape(len(trajs[4999][2]), 3, 2 * trajs[4999][0]))
 
 
 @pytest.mark.parametrize("S", [8, 11, 13, 14, 15, 16])

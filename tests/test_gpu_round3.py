@@ -161,7 +161,7 @@ def test_mixed_entry_edge_cases(csp, oracle_mod):
     assert not r.status.any()
     for i in range(B):
         o, n = int(orders[i]), int(lens[i])
-        got = r.coeffs[r.coeff_offsets[i]:r.coeff_offsets[i + 1]].reshape(n, 3, 2 * o)
+        got = r.coeffs[r.coeff_offsets[i]:r.coeff_offsets[i] + 6 * o * n].reshape(n, 3, 2 * o)
         one = csp.solve_batch(wps[i], tms[i], bc[i][None], order=o, seg_offsets=np.array([0, n]), vel_zero_weight=float(vw[i]),
                               max_segments=n, force_generic=n <= 0)
         if n <= 64 and not (o == 5 and n > 32):
