@@ -59,15 +59,20 @@ __device__ __forceinline__ void pseg_make(double T, double pw, int tau_idx, cons
     }
 }
 
-// block entries of Qt(T) + w h h^T (free derivative index r <-> endpoint-derivative index r+1)
-template <int O> __device__ __forceinline__ double q_ss(const PSeg<O> &s, double pw, int r, int c) {
-    return __builtin_fma(pw * s.h[r + 1], s.h[c + 1], Tab<O>::QT(r + 1, c + 1) * s.ip[2 * O - 3 - r - c]);
+// block entries of Qt(T) + w h h^T (free derivative index r <-> endpoint-derivative index r+1).  PEN = false (pass A, the
+// unpenalised pre-solve): the plain table entry -- h is zero there, but fma(0, 0, x) is not x to the compiler (signed zeros),
+// so the products were really issued.
+template <int O, bool PEN> __device__ __forceinline__ double q_ss(const PSeg<O> &s, double pw, int r, int c) {
+    const double q = Tab<O>::QT(r + 1, c + 1) * s.ip[2 * O - 3 - r - c];
+    return PEN ? __builtin_fma(pw * s.h[r + 1], s.h[c + 1], q) : q;
 }
-template <int O> __device__ __forceinline__ double q_se(const PSeg<O> &s, double pw, int r, int c) {
-    return __builtin_fma(pw * s.h[r + 1], s.h[O + c + 1], Tab<O>::QT(r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c]);
+template <int O, bool PEN> __device__ __forceinline__ double q_se(const PSeg<O> &s, double pw, int r, int c) {
+    const double q = Tab<O>::QT(r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c];
+    return PEN ? __builtin_fma(pw * s.h[r + 1], s.h[O + c + 1], q) : q;
 }
-template <int O> __device__ __forceinline__ double q_ee(const PSeg<O> &s, double pw, int r, int c) {
-    return __builtin_fma(pw * s.h[O + r + 1], s.h[O + c + 1], Tab<O>::QT(O + r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c]);
+template <int O, bool PEN> __device__ __forceinline__ double q_ee(const PSeg<O> &s, double pw, int r, int c) {
+    const double q = Tab<O>::QT(O + r + 1, O + c + 1) * s.ip[2 * O - 3 - r - c];
+    return PEN ? __builtin_fma(pw * s.h[O + r + 1], s.h[O + c + 1], q) : q;
 }
 
 // Dense residency (order 2, S >= 8): under 40 KB of LDS and 256 registers, so that FOUR workgroups share a CU.
@@ -204,20 +209,20 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O>(left, w, j, r);
+            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O, PEN>(left, w, j, r);
         double Sm[N][N], R[N][N + 3];
 #pragma unroll
         for (int r = 0; r < N; ++r) {
 #pragma unroll
             for (int c = 0; c <= r; ++c) {
-                double v = q_ee<O>(left, w, r, c) + q_ss<O>(right, w, r, c);
+                double v = q_ee<O, PEN>(left, w, r, c) + q_ss<O, PEN>(right, w, r, c);
                 if (r == 0 && c == 0) v += 2.0 * vw;  // both neighbours' velocity terms (:473-509)
 #pragma unroll
                 for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], W[j][c], v);
                 Sm[r][c] = v;
             }
 #pragma unroll
-            for (int c = 0; c < N; ++c) R[r][c] = q_se<O>(right, w, r, c);
+            for (int c = 0; c < N; ++c) R[r][c] = q_se<O, PEN>(right, w, r, c);
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 double v = (Tab<O>::QT(O + r + 1, 0) * left.ip[M - 2 - r]) * left.dP[ax];
@@ -251,12 +256,12 @@ __device__ __forceinline__ void path_sweep(const GenericArgs &a, int64_t b0, int
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O>(left, w, j, r);
+            for (int r = 0; r < N; ++r) seL[j][r] = q_se<O, PEN>(left, w, j, r);
 #pragma unroll
         for (int r = 0; r < N; ++r) {
 #pragma unroll
             for (int c = 0; c <= r; ++c) {
-                double v = q_ee<O>(left, w, r, c);
+                double v = q_ee<O, PEN>(left, w, r, c);
                 if (r == 0 && c == 0) v += vw;
 #pragma unroll
                 for (int j = 0; j < N; ++j) v = __builtin_fma(-seL[j][r], W[j][c], v);
