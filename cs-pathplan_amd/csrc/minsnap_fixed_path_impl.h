@@ -643,6 +643,13 @@ minsnap_fixed_path_kernel(GenericArgs a) {
     }
     CSP_STAMP_RT(5);
     CSP_STAMP(0);
+    if constexpr (!DENSE) {
+        // Orders 3-4 (and short order-2 trajectories): two workgroups per CU, one wave per SIMD.  Started together, the two
+        // compute together and then store together; the second workgroup of a CU (dispatch order: blocks 256..511 of the
+        // first round) starts a.stagger x 8128 clocks late so that one's store phase meets the other's compute.
+        if (a.stagger > 0 && gridDim.x > 256 && blockIdx.x >= 256 && blockIdx.x < 512)
+            for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+    }
     if constexpr (DENSE) {
         // A workgroup stores nothing before its backward sweep: started together, the resident workgroups compute with
         // the memory system idle and then all store at once (time = compute-before-the-first-store + bytes / bandwidth:
@@ -722,6 +729,10 @@ template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream
     // order-2 variant -- and take the same rule.
     constexpr bool WHOLE_LINES = O == 4 || LineGeom<O, S>::OK;   // incl. the dense order-2 variant (HalfRing)
     f.nt_stores = nt_forced() >= 0 ? nt_forced() : (WHOLE_LINES && big ? 1 : 0);
+    static const int stagger_env = [] { const char *e = std::getenv("CSP_PATH_STAGGER"); return e ? std::atoi(e) : -1; }();
+    // measured at B = 65536, S = 16 (tools/path_bench.py, CSP_PATH_STAGGER = 0 / 1 / 2 / 3 / 4 / 6): order 3 58.4 / 57.3 / 57.7 /
+    // 61.0 / 65.5 / 76.7 us, order 4 86.4 / 85.0 / 86.8 / 84.0 / 86.2 / 95.7 us -- a 2-3 % effect; scaled with the sweep length
+    f.stagger = stagger_env >= 0 ? stagger_env : (O == 3 ? (S + 8) / 16 : O == 4 ? (3 * S + 8) / 16 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();

@@ -50,6 +50,7 @@ struct GenericArgs {
                             // are cut into narrower slices so that every CU gets one, see fixedk::narrow_slice)
     int nt_stores = 0;      // fixed kernels, whole slices: non-temporal coefficient stores -- set by the launcher for
                             // batches whose coefficients exceed the Infinity Cache (fixedk::store16)
+    int stagger = 0;        // path kernels (orders 3-4): start delay of a CU's second workgroup, units of 8128 clocks
     const MultiTable *multi = nullptr;   // HOST pointer, launcher only: csp_minsnap_solve_multi's batches (then wp/times/bc/coeffs/
                                          // status/B above are ignored)
 };
