@@ -83,6 +83,42 @@ __device__ __forceinline__ void eval_poly(const double (&c)[3][M], double t, dou
     }
 }
 
+// The two statistics the reference PRINTS (max climb rate, min turn radius; minimum_snap.cpp:163-195) are an extremum over
+// consecutive recorded samples of dz / hd and of the circumradius la lb lc / (4 area).  Both are monotone in their squares, so
+// the kernels track the extremum of the SQUARES -- no square root and one reciprocal per quantity and sample instead of five
+// fp64 square roots and two divisions -- and take the two square roots once, when the statistics are written (round 3).
+// The reference's thresholds carry over (hd > 1e-6 <=> hd^2 > 1e-12, area > 1e-8 <=> |u x w|^2 > 4e-16); the values agree
+// with the reference's to rounding (1e-15 relative), which is what the tests ask of a printed diagnostic (1e-6); every
+// sampler uses these functions, so they agree with each other bit for bit.
+__device__ __forceinline__ double stat_rcp(double x) {   // hardware seed + two Newton steps; arguments are 1e-16 .. 1e20
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ void stat_look(const double (&p0)[3], const double (&p1)[3], const double (&p)[3], bool have1, bool have2,
+                                          double &max_climb2, double &min_r2) {
+    if (have1) {
+        const double dx = p[0] - p1[0], dy = p[1] - p1[1], dz = p[2] - p1[2];
+        const double hd2 = dx * dx + dy * dy;
+        if (hd2 > 1e-12) { const double r2 = dz * dz * stat_rcp(hd2); if (r2 > max_climb2) max_climb2 = r2; }
+        if (have2) {
+            const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+            const double w[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
+            const double la2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+            const double lb2 = hd2 + dz * dz;
+            const double lc2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+            const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
+            const double a2 = cx * cx + cy * cy + cz * cz;               // (2 area)^2
+            if (a2 > 4e-16) { const double R2 = la2 * lb2 * lc2 * 0.25 * stat_rcp(a2); if (R2 < min_r2) min_r2 = R2; }
+        }
+    }
+}
+constexpr double STAT_NO_RADIUS2 = 1.0e24;   // (1e12)^2: the reference's initial min_r
+__device__ __forceinline__ double stat_climb(double max_climb2) { return sqrt(max_climb2); }
+__device__ __forceinline__ double stat_radius(double min_r2) { return min_r2 >= STAT_NO_RADIUS2 ? 1.0e12 : sqrt(min_r2); }
+
 template <int O, typename IO>
 __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
     constexpr int M = 2 * O;
@@ -100,24 +136,10 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
     IO *out = (IO *)a.samples + b * a.capacity * 3;
     int64_t n = 0;
     double p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};  // the two most recently recorded samples
-    double max_climb = 0.0, min_r = 1.0e12;
+    double max_climb = 0.0, min_r = STAT_NO_RADIUS2;   // squares, see stat_look
     auto record = [&](const double (&p)[3]) {
         if (n < a.capacity) { out[n * 3] = (IO)p[0]; out[n * 3 + 1] = (IO)p[1]; out[n * 3 + 2] = (IO)p[2]; }
-        if (n >= 1) {  // statistics over consecutive recorded samples (:167-193)
-            const double dx = p[0] - p1[0], dy = p[1] - p1[1], dz = fabs(p[2] - p1[2]);
-            const double hd = sqrt(dx * dx + dy * dy);
-            if (hd > 1e-6) { const double r = dz / hd; if (r > max_climb) max_climb = r; }
-            if (n >= 2) {
-                const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-                const double w[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
-                const double la = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-                const double lb = sqrt(dx * dx + dy * dy + (p[2] - p1[2]) * (p[2] - p1[2]));
-                const double lc = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-                const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
-                const double area = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
-                if (area > 1e-8) { const double R = la * lb * lc / (4.0 * area); if (R < min_r) min_r = R; }
-            }
-        }
+        stat_look(p0, p1, p, n >= 1, n >= 2, max_climb, min_r);   // statistics over consecutive recorded samples (:167-193), squared
         p0[0] = p1[0]; p0[1] = p1[1]; p0[2] = p1[2];
         p1[0] = p[0]; p1[1] = p[1]; p1[2] = p[2];
         ++n;
@@ -150,7 +172,7 @@ __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) {
         }
     }
     a.counts[b] = (int32_t)n;
-    if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+    if (a.stats) { a.stats[b * 2] = stat_climb(max_climb); a.stats[b * 2 + 1] = stat_radius(min_r); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,24 +196,8 @@ struct SampleStats {
     double p0[3], p1[3];   // the two most recently recorded samples
     double max_climb, min_r;
     int64_t n;
-    // statistics of the sample about to become number n (:167-193)
-    __device__ __forceinline__ void look(const double (&p)[3]) {
-        if (n >= 1) {
-            const double dx = p[0] - p1[0], dy = p[1] - p1[1], dz = fabs(p[2] - p1[2]);
-            const double hd = sqrt(dx * dx + dy * dy);
-            if (hd > 1e-6) { const double r = dz / hd; if (r > max_climb) max_climb = r; }
-            if (n >= 2) {
-                const double u[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-                const double w[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
-                const double la = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-                const double lb = sqrt(dx * dx + dy * dy + (p[2] - p1[2]) * (p[2] - p1[2]));
-                const double lc = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-                const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2], cz = u[0] * w[1] - u[1] * w[0];
-                const double area = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
-                if (area > 1e-8) { const double R = la * lb * lc / (4.0 * area); if (R < min_r) min_r = R; }
-            }
-        }
-    }
+    // statistics of the sample about to become number n (:167-193); max_climb / min_r hold the SQUARES (stat_look)
+    __device__ __forceinline__ void look(const double (&p)[3]) { stat_look(p0, p1, p, n >= 1, n >= 2, max_climb, min_r); }
     __device__ __forceinline__ void shift(const double (&p)[3]) {
         p0[0] = p1[0]; p0[1] = p1[1]; p0[2] = p1[2];
         p1[0] = p[0]; p1[1] = p[1]; p1[2] = p[2];
@@ -274,7 +280,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
     }
     SampleStats st;
     st.max_climb = 0.0;
-    st.min_r = 1.0e12;
+    st.min_r = STAT_NO_RADIUS2;
     st.n = nbefore;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { st.p0[q] = 0.0; st.p1[q] = 0.0; }
@@ -314,7 +320,11 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
     if (active && j == S - 1) l_cnt[base] = nbefore + cnt + (add_end ? 1 : 0);
     __syncthreads();
     const int traj_total = S > 0 ? l_cnt[base] : 0;
-    const bool inline_stats = !F64 || traj_total > a.capacity || a.stats == nullptr;
+    // With the squared statistics (stat_look: ~40 instructions per recorded sample) the second pass takes them inline for
+    // every trajectory; the separate statistics kernel (one wave per trajectory re-reading the samples: two dependent memory
+    // round trips per wave, 70-90 us at B = 65536 whatever its arithmetic) is gone.
+    const bool inline_stats = a.stats != nullptr;
+    (void)F64; (void)traj_total;
 
     // ---- pass 2: evaluate and thin again, now storing ----
     IO *out = (IO *)a.samples + bb * a.capacity * 3;
@@ -346,8 +356,7 @@ __global__ void __launch_bounds__(64) sample_seg_kernel(SampleArgs a, int lpt_lo
     }
     if (traj_ok && (S == 0 ? j == 0 : j == S - 1)) {
         a.counts[b] = (int32_t)st.n;
-        // (0, 1e12) when the statistics are left to sample_stats_kernel
-        if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+        if (a.stats) { a.stats[b * 2] = stat_climb(max_climb); a.stats[b * 2 + 1] = stat_radius(min_r); }
     }
 }
 
@@ -363,7 +372,7 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
     const double *row = samples + b * capacity * 3;
     SampleStats st;
     st.max_climb = 0.0;
-    st.min_r = 1.0e12;
+    st.min_r = STAT_NO_RADIUS2;
     for (int i = lane; i < n; i += 64) {
         double p[3];
 #pragma unroll
@@ -381,7 +390,7 @@ __global__ void __launch_bounds__(256) sample_stats_kernel(const double *samples
         max_climb = oc > max_climb ? oc : max_climb;
         min_r = orr < min_r ? orr : min_r;
     }
-    if (lane == 0) { stats[b * 2] = max_climb; stats[b * 2 + 1] = min_r; }
+    if (lane == 0) { stats[b * 2] = stat_climb(max_climb); stats[b * 2 + 1] = stat_radius(min_r); }
 }
 
 // Candidate times are ACCUMULATED (t += dt, minimum_snap.cpp:136) and their rounding decides which candidates exist
@@ -431,7 +440,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a, const dou
     IO *out = (IO *)a.samples + b * a.capacity * 3;
     SampleStats st;          // per-lane partial max / min; p0, p1, n are filled per sample in flush()
     st.max_climb = 0.0;
-    st.min_r = 1.0e12;
+    st.min_r = STAT_NO_RADIUS2;
     int64_t n = 0;           // samples recorded so far (wave-uniform)
     int nb = 0;              // of which queued in the ring
     double last[3] = {0, 0, 0};   // the most recently recorded sample (wave-uniform)
@@ -584,7 +593,7 @@ __global__ void __launch_bounds__(64) sample_wave_kernel(SampleArgs a, const dou
     }
     if (lane == 0) {
         a.counts[b] = (int32_t)n;
-        if (a.stats) { a.stats[b * 2] = max_climb; a.stats[b * 2 + 1] = min_r; }
+        if (a.stats) { a.stats[b * 2] = stat_climb(max_climb); a.stats[b * 2 + 1] = stat_radius(min_r); }
     }
 }
 
@@ -789,7 +798,7 @@ __global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const d
         __syncthreads();
         SampleStats st;
         st.max_climb = 0.0;
-        st.min_r = 1.0e12;
+        st.min_r = STAT_NO_RADIUS2;
         for (int64_t i = tid; i < n; i += 256) {
             double p[3];
 #pragma unroll
@@ -814,8 +823,8 @@ __global__ void __launch_bounds__(256) sample_place_kernel(SampleArgs a, const d
                 max_climb = l_red[w] > max_climb ? l_red[w] : max_climb;
                 min_r = l_red[4 + w] < min_r ? l_red[4 + w] : min_r;
             }
-            a.stats[b * 2] = max_climb;
-            a.stats[b * 2 + 1] = min_r;
+            a.stats[b * 2] = stat_climb(max_climb);
+            a.stats[b * 2 + 1] = stat_radius(min_r);
         }
     }
 }
@@ -888,9 +897,6 @@ template <typename IO> static hipError_t launch_sample_t(const SampleArgs &a, hi
             case 5: hipLaunchKernelGGL((sample_seg_kernel<5, IO>), grid, block, 0, st, a, l); break;
             default: return hipErrorInvalidValue;
         }
-        if (sizeof(IO) == 8 && a.stats)
-            hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, st, (const double *)a.samples,
-                               a.counts, a.stats, a.B, a.capacity);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)((a.B + 63) / 64)), block(64);
