@@ -333,3 +333,35 @@ def test_keep_decision_ulp_band_is_recorded(csp, oracle_mod):
     print("keep-decision ulp band (HIP power ladder vs the oracle's pow):", rec)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rec, open(os.path.join("gpurun_out", "ulp_band.json"), "w"))
+
+
+def test_device_memory_calls_can_be_captured_in_a_hip_graph(csp):
+    """CSP_MEM_DEVICE calls only enqueue work on the caller's stream, so a planner can capture its per-tick solves in a HIP
+    graph: 8 small solves and a path-penalty solve captured once and replayed, bit-equal with the eager calls.  (A graph
+    removes host launch cost, not the kernels' own ~6 us latency: 16 x C2 replay at 6.4 us per batch against 1.8 us through
+    csp_minsnap_solve_multi's single launch -- tools/graph_probe.py.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    preps = []
+    for k in range(8):
+        wp, tm = synth.make_batch(1000 + 37 * k, 8, config_id=2, offset=5000 * k)
+        preps.append(csp.PreparedSolve(torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev), order=4))
+    wp, tm = synth.make_batch(3000, 16, config_id=3)
+    preps.append(csp.PreparedSolve(torch.from_numpy(wp).to(dev), torch.from_numpy(tm).to(dev), order=2, path_weight=1e-3, vel_zero_weight=0.01))
+    for p in preps:
+        p.run()
+    torch.cuda.synchronize()
+    ref = [p.out.clone() for p in preps]
+    for p in preps:
+        p.out.zero_()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for p in preps:
+                p.run(stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.out) for a, p in zip(ref, preps))
