@@ -658,7 +658,7 @@ minsnap_fixed_path_kernel(GenericArgs a) {
         // 0 / 2 S / 4 S / 6 S / 8 S x 64 clocks: 40.1 / 39.9 / 37.7 / 37.2 / 38.2 us).  First round only -- later rounds
         // are out of step by themselves -- and never for grids of <= 256 workgroups.
         const int slot = blockIdx.x < 1024 ? (int)(blockIdx.x >> 8) : 0;
-        for (int q = 0; q < slot; ++q) __builtin_amdgcn_s_sleep(6 * S < 127 ? 6 * S : 127);
+        for (int q = 0; q < slot * a.stagger; ++q) __builtin_amdgcn_s_sleep(S < 127 ? S : 127);   // a.stagger x S x 64 clocks per slot
     }
     {
         const double2 *g_wp = reinterpret_cast<const double2 *>((const double *)a.wp + b0 * L::WP_ROW);
@@ -732,7 +732,9 @@ template <int O, int S> hipError_t launch_path_s(const GenericArgs &a, hipStream
     static const int stagger_env = [] { const char *e = std::getenv("CSP_PATH_STAGGER"); return e ? std::atoi(e) : -1; }();
     // measured at B = 65536, S = 16 (tools/path_bench.py, CSP_PATH_STAGGER = 0 / 1 / 2 / 3 / 4 / 6): order 3 58.4 / 57.3 / 57.7 /
     // 61.0 / 65.5 / 76.7 us, order 4 86.4 / 85.0 / 86.8 / 84.0 / 86.2 / 95.7 us -- a 2-3 % effect; scaled with the sweep length
-    f.stagger = stagger_env >= 0 ? stagger_env : (O == 3 ? (S + 8) / 16 : O == 4 ? (3 * S + 8) / 16 : 0);
+    // (dense order-2 variant: the four workgroups of a CU start stagger x S x 64 clocks apart; with the closed-form search of
+    // round 3 -- CSP_PATH_STAGGER = 0 / 2 / 3 / 4 / 5 / 6 / 8: 33.2 / 30.6 / 30.2 / 30.3 / 30.3 / 30.8 / 32.1 us at B = 65536, S = 16)
+    f.stagger = stagger_env >= 0 ? stagger_env : (path_dense<O, S> ? 4 : O == 3 ? (S + 8) / 16 : O == 4 ? (3 * S + 8) / 16 : 0);
     if (a.status) hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, true>), grid, block, 0, st, f);
     else hipLaunchKernelGGL((minsnap_fixed_path_kernel<O, S, false>), grid, block, 0, st, f);
     return hipGetLastError();
