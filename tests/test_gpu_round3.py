@@ -365,3 +365,23 @@ def test_device_memory_calls_can_be_captured_in_a_hip_graph(csp):
         g.replay()
     torch.cuda.synchronize()
     assert all(torch.equal(a, p.out) for a, p in zip(ref, preps))
+
+
+def test_hip_against_the_60_digit_kkt_solution(csp):
+    """F8: the constrained QP solved directly in 60-digit arithmetic (oracle/gen_golden_kkt.py) -- an independent yardstick that
+    shares nothing with the closed form's algebra or with either restatement's rounding.  Every HIP kernel family that serves
+    the case (register-resident, generic) against it, per power; the errors are printed."""
+    from tests.conftest import load_cases
+    worst = {}
+    for c in load_cases("F8_kkt_mpmath.json"):
+        for force in (False, True):
+            r = csp.solve_batch(c["path"][None], c["time"][None], c["bc"][None], order=c["order"], vel_zero_weight=c["vel_zero_weight"],
+                                want_status=True, force_generic=force)
+            assert int(r.status[0]) == 0
+            # measured (round 3): <= 3e-15 / 9e-14 / 9e-13 / 1.9e-11 per power at orders 2 / 3 / 4 / 5 -- three orders of magnitude
+            # closer to the exact QP solution than the fp64 dense restatement of the reference's algorithm is (3.8e-8)
+            tol = 5e-10 if c["order"] == 5 else 1e-11
+            pp, _ = synth.parity_gate(r.coeffs[0], c["coeff"], tol, ("HIP vs 60-digit KKT", c["name"], r.kernel))
+            key = (c["order"], "generic" if force else r.kernel.split("_")[0])
+            worst[key] = max(worst.get(key, 0.0), pp)
+    print("HIP vs the 60-digit KKT solution, worst per-power error by (order, kernel family):", worst)

@@ -12,7 +12,7 @@ from oracle import numpy_ref as nr
 from tests import synth
 from tests.conftest import load_cases
 
-ALL = ["F1_kat.json", "F2_readme_uav31.json", "F2b_readme_uav31_merged.json", "F3_wellscaled.json", "F5_ragged.json", "F6_penalties.json"]
+ALL = ["F1_kat.json", "F2_readme_uav31.json", "F2b_readme_uav31_merged.json", "F8_kkt_mpmath.json", "F3_wellscaled.json", "F5_ragged.json", "F6_penalties.json"]
 
 
 def _rel(a, b):
@@ -174,3 +174,26 @@ def test_structured_cpu_solver_matches_the_dense_oracle(order):
     one = oracle.struct_solve_batch(order, wp[:1], tm[:1], None)
     ld, _ = oracle.solve_batch(order, wp[:1], tm[:1], long_double=True)
     assert synth.rel_err(one, ld) < 1e-9
+
+
+def test_closed_form_is_the_minimiser_of_the_constrained_qp():
+    """F8 (oracle/gen_golden_kkt.py): the constrained QP behind the reference's closed form -- snap integral [+ zero-velocity
+    penalty] subject to interpolation, continuity of derivatives 1..o-1 and pinned end derivatives -- solved DIRECTLY through
+    its KKT system in 60-digit arithmetic, no M inverse, no selection matrix.  Both restatements of the closed form (numpy,
+    C) and the 80-bit build agree with it per power to their own rounding: the algebra of SURVEY.md rows A4-A10 is the QP's.
+    (Says nothing about Eigen's rounding: parity stays unpinned.)"""
+    worst = {"numpy": 0.0, "c_f64": 0.0, "c_ld": 0.0}
+    for c in load_cases("F8_kkt_mpmath.json"):
+        S, m = c["segments"], 2 * c["order"]
+        kkt = c["coeff"].reshape(S, 3, m)
+        npy, _ = nr.solve_qp_closed_form(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"])
+        f64, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"])
+        ld, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"], long_double=True)
+        e = {"numpy": synth.rel_err_per_power(np.asarray(npy).reshape(kkt.shape), kkt), "c_f64": synth.rel_err_per_power(f64.reshape(kkt.shape), kkt),
+             "c_ld": synth.rel_err_per_power(ld.reshape(kkt.shape), kkt)}
+        tol = 1e-6 if c["order"] == 5 else (1e-9 if c["cond_M"] < 1e12 else 1e-6)
+        assert e["numpy"] < tol and e["c_f64"] < tol, (c["name"], e)
+        assert e["c_ld"] < (1e-9 if c["order"] == 5 else 1e-11) or c["cond_M"] >= 1e12, (c["name"], e)
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+    print("closed form vs the 60-digit KKT solution, worst per-power error:", worst)
