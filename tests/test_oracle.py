@@ -178,7 +178,7 @@ def test_structured_cpu_solver_matches_the_dense_oracle(order):
 
 def test_closed_form_is_the_minimiser_of_the_constrained_qp():
     """F8 (oracle/gen_golden_kkt.py): the constrained QP behind the reference's closed form -- snap integral [+ zero-velocity
-    penalty] subject to interpolation, continuity of derivatives 1..o-1 and pinned end derivatives -- solved DIRECTLY through
+    penalty, + the path penalty in its two-stage form with the un-halved linear term, minimum_snap.cpp:347-469, :577-579] subject to interpolation, continuity of derivatives 1..o-1 and pinned end derivatives -- solved DIRECTLY through
     its KKT system in 60-digit arithmetic, no M inverse, no selection matrix.  Both restatements of the closed form (numpy,
     C) and the 80-bit build agree with it per power to their own rounding: the algebra of SURVEY.md rows A4-A10 is the QP's.
     (Says nothing about Eigen's rounding: parity stays unpinned.)"""
@@ -186,9 +186,10 @@ def test_closed_form_is_the_minimiser_of_the_constrained_qp():
     for c in load_cases("F8_kkt_mpmath.json"):
         S, m = c["segments"], 2 * c["order"]
         kkt = c["coeff"].reshape(S, 3, m)
-        npy, _ = nr.solve_qp_closed_form(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"])
-        f64, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"])
-        ld, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], 0.0, c["vel_zero_weight"], long_double=True)
+        pw = c["path_weight"]     # > 0: the two-stage definition with the un-halved linear term, t* from the 60-digit pre-solve
+        npy, _ = nr.solve_qp_closed_form(c["order"], c["path"], c["vel"], c["acc"], c["time"], pw, c["vel_zero_weight"])
+        f64, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], pw, c["vel_zero_weight"])
+        ld, _ = oracle.solve(c["order"], c["path"], c["vel"], c["acc"], c["time"], pw, c["vel_zero_weight"], long_double=True)
         e = {"numpy": synth.rel_err_per_power(np.asarray(npy).reshape(kkt.shape), kkt), "c_f64": synth.rel_err_per_power(f64.reshape(kkt.shape), kkt),
              "c_ld": synth.rel_err_per_power(ld.reshape(kkt.shape), kkt)}
         tol = 1e-6 if c["order"] == 5 else (1e-9 if c["cond_M"] < 1e12 else 1e-6)
