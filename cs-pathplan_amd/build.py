@@ -12,10 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcsp_minsnap.so")
-SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_chunked.hip", "minsnap_mixed.hip", "minsnap_span.hip", "minsnap_fixed.hip", "minsnap_fixed_o2.hip", "minsnap_fixed_o3.hip",
+SOURCES = ["minsnap_capi.hip", "minsnap_generic.hip", "minsnap_chunked.hip", "minsnap_mixed.hip", "minsnap_twist.hip", "minsnap_twist_f32.hip", "minsnap_twist_f32s.hip", "minsnap_twist_f64.hip", "minsnap_twist_f64s.hip", "minsnap_span.hip", "minsnap_fixed.hip", "minsnap_fixed_o2.hip", "minsnap_fixed_o3.hip",
            "minsnap_fixed_o4a.hip", "minsnap_fixed_o4b.hip", "minsnap_fixed_o5.hip",
            "minsnap_fixedpath_o2.hip", "minsnap_fixedpath_o3.hip", "minsnap_fixedpath_o4a.hip", "minsnap_fixedpath_o4b.hip", "minsnap_timealloc.hip", "minsnap_plan.hip", "geo.hip", "alt.hip", "bezier.hip"]
-HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_hoststage.h", "minsnap_timealloc.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h", "minsnap_chunked_impl.h", "minsnap_mixed.h", "minsnap_shard_schedule.h",
+HEADERS = ["minsnap_device.h", "minsnap_launch.h", "minsnap_hoststage.h", "minsnap_timealloc.h", "minsnap_tables.h", "minsnap_fixed_impl.h", "minsnap_fixed_path_impl.h", "minsnap_iface.h", "minsnap_chunked_impl.h", "minsnap_mixed.h", "minsnap_twist_impl.h", "minsnap_twist_launch.h", "minsnap_shard_schedule.h",
            os.path.join("..", "..", "include", "csp_minsnap.h"), os.path.join("..", "..", "include", "csp_geo.h"), os.path.join("..", "..", "include", "csp_alt.h"), os.path.join("..", "..", "include", "csp_bezier.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]

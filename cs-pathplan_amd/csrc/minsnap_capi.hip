@@ -626,7 +626,7 @@ int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *
 
 size_t csp_minsnap_mixed_workspace_bytes(const csp_minsnap_desc *desc) {
     if (!desc || desc->batch < 0) return 0;
-    return csp::mixed_workspace_bytes(desc->batch);
+    return csp::mixed_workspace_bytes(desc->batch, desc->max_segments);
 }
 
 int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders, const void *waypoints, const void *times,
@@ -647,12 +647,12 @@ int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders,
     const bool f32 = desc->dtype == CSP_DTYPE_F32;
     const size_t elt = f32 ? 4 : 8;
     const int64_t B = desc->batch;
-    const size_t need = csp::mixed_workspace_bytes(B);
+    const size_t need = csp::mixed_workspace_bytes(B, desc->max_segments);
     csp::GenericArgs a;
     a.max_dev = nullptr; a.ws = nullptr; a.tstar = nullptr;
     a.path_weight = 0.0;
     a.vel_zero_weight = desc->vel_zero_weight;
-    a.B = B; a.S = 0; a.order = 0; a.bc_per_traj = desc->bc_per_trajectory ? 1 : 0;
+    a.B = B; a.S = desc->max_segments; a.order = 0; a.bc_per_traj = desc->bc_per_trajectory ? 1 : 0;
     a.seg_major = 0; a.Btotal = B; a.Boffset = 0; a.persistent = 1; a.skip = nullptr; a.tau_mode = 0;
     if (desc->mem_space == CSP_MEM_DEVICE) {
         if (!workspace || workspace_bytes < need) return CSP_ERR_WORKSPACE;

@@ -71,10 +71,10 @@ int chunked_lanes_log2(int Smax);
 hipError_t launch_chunked(const GenericArgs &a, bool f32, int Smax, hipStream_t st);
 
 // Mixed-ORDER ragged batches (minsnap_mixed.hip): device-side bucketing by (order, length class), one persistent launch per
-// order, inputs read and coefficients written in the caller's order.  a.seg_off, a.B, a.wp/times/bc/coeffs/status, a.vw_per
-// and the weights are used; `orders` is [B] int32 on the device; `workspace` >= mixed_workspace_bytes(B); coef_off_out:
+// order, inputs read and coefficients written in the caller's order.  a.seg_off, a.B, a.S (= the caller's max_segments),
+// a.wp/times/bc/coeffs/status, a.vw_per and the weights are used; `orders` is [B] int32 on the device; `workspace` >= mixed_workspace_bytes(B, a.S); coef_off_out:
 // optional [B+1] int64 (element offsets of every trajectory's coefficient block).
-size_t mixed_workspace_bytes(int64_t B);
+size_t mixed_workspace_bytes(int64_t B, int max_segments);
 hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, void *workspace, int64_t *coef_off_out, hipStream_t st);
 
 // Long trajectories (16 < S <= 1024): spans of 16 segments per lane, recovery by recomputation

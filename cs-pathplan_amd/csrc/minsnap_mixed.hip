@@ -16,17 +16,23 @@
 // arithmetic is that of csp_minsnap_solve_batch on the same order and length class (bit-equal: tests/test_gpu_round3.py).
 #include "minsnap_chunked_impl.h"
 #include "minsnap_mixed.h"
+#include "minsnap_twist_launch.h"
 
 #include <cstdlib>
 
 namespace csp {
 namespace mixed {
 
-constexpr int NCLS = 64;         // class k <-> 64 - k lanes per trajectory (one lane per chunk of <= 4 segments): longest first
+static __constant__ TwistCostOrder g_cost_order = make_twist_cost_order();
+
+constexpr int NCLS = MIXED_NCLS;
 constexpr int NORD = 4;          // orders 2..5
+constexpr int NGRP = MIXED_NGRP; // (family, order): family 0 = the lane-pair sweep (S <= 64), family 1 = the chunked kernel (65 .. 256)
+constexpr int NKEY = NGRP * NCLS;
 constexpr int ITEMS = 4;         // trajectories per thread of the bucketing kernels
 constexpr int BT = 256;          // threads per bucketing block
-static_assert(BT == NORD * NCLS, "the planning block has one thread per (order, class) key");
+constexpr int PT = NKEY;         // threads of the planning block: one per (group, class) key
+static_assert(PT == 512, "the planning block's scans are written for eight waves");
 
 // lanes a trajectory of S segments gets: one per chunk of <= 4 segments.  (The one-order kernel rounds this up to a power
 // of two and gives a whole call the lanes of its longest trajectory; here the classes are exact, so a 33-segment trajectory
@@ -43,20 +49,23 @@ __device__ __forceinline__ long long block_elems(int o, int64_t S, int pad_to) {
     return (n + pad_to - 1) / pad_to * pad_to;
 }
 
-// key = order index * NCLS + class, or -1 for a trajectory this path does not serve (order outside 2..5, S outside 1..256)
-__device__ __forceinline__ int key_of(int order, int64_t S) {
-    if (order < 2 || order > 5 || S < 1 || S > chunked::CMAX * 64) return -1;
-    return (order - 2) * NCLS + (64 - lanes_of((int)S));
+// key = group * NCLS + class, or -1 for a trajectory this path does not serve (order outside 2..5, S outside 1..smax).
+// twist_mask bit (order - 2): trajectories of up to 64 segments of that order go to the lane-pair sweep.
+__device__ __forceinline__ int key_of(int order, int64_t S, int smax, int twist_mask) {
+    if (order < 2 || order > 5 || S < 1 || S > chunked::CMAX * 64 || S > smax) return -1;
+    if (S <= twist::SMAX && ((twist_mask >> (order - 2)) & 1)) return (order - 2) * NCLS + (twist::SMAX - (int)S);
+    return (NORD + order - 2) * NCLS + (64 - lanes_of((int)S));
 }
 
 // No global atomics anywhere in the bucketing: same-address device-scope atomics cost ~60 ns EACH on this part (measured:
 // a first version whose persistent waves pulled work units from one counter spent 1.2 ms on 20 k atomicAdds, whatever
 // the work), so blocks publish their histograms and the planning block turns them into per-block offsets.
-__global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, int32_t *hist_blk, int64_t *block_sum, int pad_to) {
-    __shared__ int hist[NORD * NCLS];
+__global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, int32_t *hist_blk, int64_t *block_sum, int pad_to,
+                                                   int smax, int twist_mask) {
+    __shared__ int hist[NKEY];
     __shared__ long long wsum[BT / 64];
     const int tid = threadIdx.x;
-    if (tid < NORD * NCLS) hist[tid] = 0;
+    for (int q = tid; q < NKEY; q += BT) hist[q] = 0;
     __syncthreads();
     long long csz = 0;
 #pragma unroll
@@ -65,7 +74,7 @@ __global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const 
         if (i < B) {
             const int o = orders[i];
             const int64_t S = seg_off[i + 1] - seg_off[i];
-            const int k = key_of(o, S);
+            const int k = key_of(o, S, smax, twist_mask);
             if (k >= 0) atomicAdd(&hist[k], 1);
             // the coefficient block exists in the caller's layout whether or not the trajectory is served
             csz += block_elems(o, S, pad_to);
@@ -75,7 +84,7 @@ __global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const 
     for (int d = 32; d >= 1; d >>= 1) csz += __shfl_xor(csz, d);
     if ((tid & 63) == 0) wsum[tid >> 6] = csz;
     __syncthreads();
-    if (tid < NORD * NCLS) hist_blk[(int64_t)blockIdx.x * (NORD * NCLS) + tid] = hist[tid];
+    for (int q = tid; q < NKEY; q += BT) hist_blk[(int64_t)blockIdx.x * NKEY + q] = hist[q];
     if (tid == 0) {
         long long s = 0;
         for (int w = 0; w < BT / 64; ++w) s += wsum[w];
@@ -84,22 +93,22 @@ __global__ void __launch_bounds__(BT) count_kernel(const int32_t *orders, const 
 }
 
 // one block: bucket starts / work units per order, exclusive scan of the per-block coefficient sizes
-__global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist_blk, int64_t *block_sum, int64_t nblk, int64_t *coef_off, int64_t B) {
+__global__ void __launch_bounds__(PT) plan_kernel(MixedTable *tab, int32_t *hist_blk, int64_t *block_sum, int64_t nblk, int64_t *coef_off, int64_t B) {
     __shared__ long long carry;
-    __shared__ long long wtot[BT / 64];
-    __shared__ int total[NORD * NCLS];
+    __shared__ long long wtot[PT / 64];
+    __shared__ int total[NKEY];
     const int tid = threadIdx.x;
     // per key: exclusive scan over the blocks of that key's counts (in place: hist_blk becomes the block's offset inside its
     // bucket); loads batched eight at a time
-    if (tid < NORD * NCLS) {
+    {
         int run = 0;
         for (int64_t b0 = 0; b0 < nblk; b0 += 8) {
             int v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = b0 + q < nblk ? hist_blk[(b0 + q) * (NORD * NCLS) + tid] : 0;
+            for (int q = 0; q < 8; ++q) v[q] = b0 + q < nblk ? hist_blk[(b0 + q) * NKEY + tid] : 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (b0 + q < nblk) hist_blk[(b0 + q) * (NORD * NCLS) + tid] = run;
+                if (b0 + q < nblk) hist_blk[(b0 + q) * NKEY + tid] = run;
                 run += v[q];
             }
         }
@@ -107,13 +116,13 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
         tab->count[tid] = run;
     }
     if (tid == 0) carry = 0;
-    // bucket starts (exclusive scan of the 256 totals, orders back to back) and work units per order (one order = the 64
-    // classes = one wave: a wave-level scan).  In parallel: one thread walking the 256 entries with a global store each took
+    // bucket starts (exclusive scan of the 512 totals, groups back to back) and work units per group (one group = the 64
+    // classes = one wave: a wave-level scan).  In parallel: one thread walking the entries with a global store each took
     // 36 us -- an eighth of the C5 call.
     {
-        const int o = tid >> 6, k = tid & 63;          // BT = 256 = NORD * NCLS: thread = key
+        const int o = tid >> 6, k = tid & 63;          // PT = NGRP * NCLS: thread = key, wave = group
         const int n = total[tid];
-        const int per_wave = 64 / (64 - k);            // trajectories per 64-lane work unit
+        const int per_wave = o < NORD ? 64 : 64 / (64 - k);   // trajectories per work unit
         const int units = (n + per_wave - 1) / per_wave;
         int xn = n, xu = units;
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
             const int yn = __shfl_up(xn, d), yu = __shfl_up(xu, d);
             if (k >= d) { xn += yn; xu += yu; }
         }
-        __shared__ int wave_n[NORD];
+        __shared__ int wave_n[NGRP];
         if (k == 63) wave_n[o] = xn;
         __syncthreads();
         int before = 0;                                 // trajectories of the orders before mine
@@ -131,12 +140,33 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
         if (k == 63) {
             tab->bucket_start[o][NCLS] = before + xn;
             tab->unit_start[o][NCLS] = xu;
-            if (o == NORD - 1) tab->served = before + xn;
+            if (o == NGRP - 1) tab->served = before + xn;
         }
     }
+    // the lane-pair sweep's units in cost order (threads 0..255 = positions of that order: four waves)
+    {
+        __shared__ int wave_u[4];
+        const int key = tid < 4 * NCLS ? g_cost_order.key_at[tid] : 0;
+        const int units = tid < 4 * NCLS ? (total[key] + 63) / 64 : 0;
+        int x = units;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if ((tid & 63) >= d) x += y;
+        }
+        if (tid < 4 * NCLS && (tid & 63) == 63) wave_u[tid >> 6] = x;
+        __syncthreads();
+        if (tid < 4 * NCLS) {
+            int before = 0;
+            for (int w = 0; w < (tid >> 6); ++w) before += wave_u[w];
+            tab->tw_ustart[tid] = before + x - units;
+            if (tid == 4 * NCLS - 1) tab->tw_ustart[4 * NCLS] = before + x;
+        }
+        if (tid == 0) tab->next_unit = 0;
+    }
     __syncthreads();
-    // exclusive scan of block_sum, BT entries per round
-    for (int64_t base = 0; base < nblk; base += BT) {
+    // exclusive scan of block_sum, PT entries per round
+    for (int64_t base = 0; base < nblk; base += PT) {
         const int64_t i = base + tid;
         long long v = i < nblk ? block_sum[i] : 0, x = v;
 #pragma unroll
@@ -150,7 +180,7 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
         for (int w = 0; w < (tid >> 6); ++w) pre += wtot[w];
         if (i < nblk) block_sum[i] = pre + x - v;
         __syncthreads();
-        if (tid == BT - 1) carry = pre + x;
+        if (tid == PT - 1) carry = pre + x;
         __syncthreads();
     }
     if (tid == 0) coef_off[B] = carry;
@@ -158,11 +188,11 @@ __global__ void __launch_bounds__(BT) plan_kernel(MixedTable *tab, int32_t *hist
 
 __global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, const int64_t *seg_off, int64_t B, const MixedTable *tab,
                                                      const int32_t *blk_base, const int64_t *block_pre, int64_t *coef_off, int32_t *perm,
-                                                     int32_t *status, int pad_to) {
-    __shared__ int hist[NORD * NCLS], base[NORD * NCLS];
+                                                     int32_t *status, int pad_to, int smax, int twist_mask) {
+    __shared__ int hist[NKEY], base[NKEY];
     __shared__ long long wtot[BT / 64];
     const int tid = threadIdx.x;
-    if (tid < NORD * NCLS) hist[tid] = 0;
+    for (int q = tid; q < NKEY; q += BT) hist[q] = 0;
     __syncthreads();
     int key[ITEMS], rank[ITEMS];
     long long csz[ITEMS], mine = 0;
@@ -177,7 +207,7 @@ __global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, cons
         if (i < B) {
             const int o = orders[i];
             const int64_t S = seg_off[i + 1] - seg_off[i];
-            key[it] = key_of(o, S);
+            key[it] = key_of(o, S, smax, twist_mask);
             csz[it] = block_elems(o, S, pad_to);
             if (key[it] >= 0) rank[it] = atomicAdd(&hist[key[it]], 1);
             if (status) status[i] = key[it] >= 0 ? 0 : CSP_TRAJ_SKIPPED_BIT;   // the solve kernels OR their bits in
@@ -192,7 +222,7 @@ __global__ void __launch_bounds__(BT) scatter_kernel(const int32_t *orders, cons
     }
     if ((tid & 63) == 63) wtot[tid >> 6] = x;
     __syncthreads();
-    if (tid < NORD * NCLS) base[tid] = blk_base[(int64_t)blockIdx.x * (NORD * NCLS) + tid];
+    for (int q = tid; q < NKEY; q += BT) base[q] = blk_base[(int64_t)blockIdx.x * NKEY + q];
     long long pre = block_pre[blockIdx.x] + x - mine;
     for (int w = 0; w < (tid >> 6); ++w) pre += wtot[w];
     __syncthreads();
@@ -221,7 +251,7 @@ minsnap_chunked_mixed_kernel(GenericArgs a, const int32_t *perm, const int64_t *
     __shared__ double xch[3 * (O - 1) * 64];
     __shared__ int s_ustart[NCLS + 1], s_bstart[NCLS + 1];
     const int lane = threadIdx.x;
-    constexpr int oi = O - 2;
+    constexpr int oi = NORD + O - 2;   // group: chunked family, this order
     s_ustart[lane] = tab->unit_start[oi][lane];
     s_bstart[lane] = tab->bucket_start[oi][lane];
     if (lane == 0) { s_ustart[NCLS] = tab->unit_start[oi][NCLS]; s_bstart[NCLS] = tab->bucket_start[oi][NCLS]; }
@@ -264,10 +294,37 @@ template <int O> hipError_t launch_order(const GenericArgs &a, bool f32, const i
 
 }  // namespace mixed
 
-size_t mixed_workspace_bytes(int64_t B) {
+// checkpoint slots of the lane-pair sweep: one per persistent workgroup, sized for the order that needs most at the
+// caller's max_segments (a role of ceil(smax / 2) segments keeps one checkpoint per block boundary)
+namespace {
+constexpr int TWIST_MAX_WG = 512;
+template <int O> size_t twist_role_doubles(int smax) {
+    using G = twist::Geo<O>;
+    const int hs = ((smax < twist::SMAX ? smax : twist::SMAX) + 1) / 2;
+    const int nck = (hs + G::K - 1) / G::K - 1;
+    return (size_t)(nck > 0 ? nck : 0) * G::CKD * 64;
+}
+size_t twist_slot_doubles_per_role(int smax) {
+    size_t m = twist_role_doubles<2>(smax);
+    if (twist_role_doubles<3>(smax) > m) m = twist_role_doubles<3>(smax);
+    if (twist_role_doubles<4>(smax) > m) m = twist_role_doubles<4>(smax);
+    if (twist_role_doubles<5>(smax) > m) m = twist_role_doubles<5>(smax);
+    return m + 64;   // never empty
+}
+// a work unit holds at least one trajectory; every (order, S) class ends in at most one partial unit
+int twist_slots(int64_t B) {
+    int64_t n = B / 64 + mixed::NORD * mixed::NCLS;
+    if (n > B) n = B;
+    if (n > TWIST_MAX_WG) n = TWIST_MAX_WG;
+    return (int)n;
+}
+}  // namespace
+
+size_t mixed_workspace_bytes(int64_t B, int smax) {
     const int64_t nblk = (B + mixed::BT * mixed::ITEMS - 1) / (mixed::BT * mixed::ITEMS);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    return up(sizeof(MixedTable)) + up((size_t)(nblk + 1) * 8) + up((size_t)nblk * 4 * mixed::NCLS * 4) + up((size_t)(B + 1) * 8) + up((size_t)B * 4);
+    return up(sizeof(MixedTable)) + up((size_t)(nblk + 1) * 8) + up((size_t)nblk * mixed::NKEY * 4) + up((size_t)(B + 1) * 8) + up((size_t)B * 4) +
+           up((size_t)twist_slots(B) * twist_slot_doubles_per_role(smax) * 2 * sizeof(double));
 }
 
 // Forked streams of one device for the per-order launches (created once per device and thread, never destroyed: the
@@ -304,16 +361,23 @@ hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, v
     char *w = (char *)workspace;
     MixedTable *tab = (MixedTable *)w;                 w += up(sizeof(MixedTable));
     int64_t *block_sum = (int64_t *)w;                 w += up((size_t)(nblk + 1) * 8);
-    int32_t *hist_blk = (int32_t *)w;                  w += up((size_t)nblk * NORD * NCLS * 4);
+    int32_t *hist_blk = (int32_t *)w;                  w += up((size_t)nblk * NKEY * 4);
     int64_t *coef_ws = (int64_t *)w;                   w += up((size_t)(B + 1) * 8);
-    int32_t *perm = (int32_t *)w;
+    int32_t *perm = (int32_t *)w;                      w += up((size_t)B * 4);
+    double *ckws = (double *)w;
     int64_t *coef_off = coef_off_out ? coef_off_out : coef_ws;
     hipError_t e;
     // no memsets: the three kernels write every word they or the solve read (status included)
     const int pad_to = f32 ? 4 : 2;
-    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, hist_blk, block_sum, pad_to);
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(BT), 0, st, tab, hist_blk, block_sum, nblk, coef_off, B);
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, tab, hist_blk, block_sum, coef_off, perm, a.status, pad_to);
+    const int smax = a.S > 0 ? a.S : chunked::CMAX * 64;   // the caller's max_segments: longer trajectories are skipped
+    // bit (order - 2): that order's trajectories of up to 64 segments go to the lane-pair sweep (minsnap_twist_impl.h), the
+    // longer ones to the chunked kernels.  Default: all four orders; CSP_MIXED_TWIST=0 puts everything on the chunked kernels
+    // (the round-3 baseline, tools/twist_probe.py measures one against the other)
+    static const int twist_mask = [] { const char *e = std::getenv("CSP_MIXED_TWIST"); return e ? (int)std::strtol(e, nullptr, 0) & 15 : 15; }();
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, hist_blk, block_sum, pad_to, smax, twist_mask);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PT), 0, st, tab, hist_blk, block_sum, nblk, coef_off, B);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nblk), dim3(BT), 0, st, orders, a.seg_off, B, tab, hist_blk, block_sum, coef_off, perm, a.status, pad_to,
+                       smax, twist_mask);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // persistent grids: what one order can keep resident (CUs x SIMDs x waves per SIMD), capped by the work there can be
     static int cus = 0;
@@ -329,6 +393,13 @@ hipError_t launch_mixed(const GenericArgs &a, bool f32, const int32_t *orders, v
     // queues costs tens of microseconds); default: one after the other on the caller's stream
     static const bool fork = [] { const char *e = std::getenv("CSP_MIXED_FORK"); return e && e[0] == '1'; }();
     Fork *f = fork ? fork_for_device() : nullptr;
+    if (twist_mask) {
+        int wgs = cus * 2;   // one wave per SIMD: two workgroups of two waves per CU
+        const int slots = twist_slots(B);
+        if (wgs > slots) wgs = slots;
+        if ((e = twist::launch_twist(a, f32, perm, coef_off, tab, ckws, twist_slot_doubles_per_role(smax), wgs, st)) != hipSuccess) return e;
+        if (twist_mask == 15 && smax <= twist::SMAX) return hipSuccess;   // nothing can be left for the chunked kernels
+    }
     if (!f) {   // no side streams: the four orders one after the other on the caller's stream
         if ((e = launch_order<5>(a, f32, perm, coef_off, tab, waves_for(1), st)) != hipSuccess) return e;
         if ((e = launch_order<4>(a, f32, perm, coef_off, tab, waves_for(2), st)) != hipSuccess) return e;

@@ -53,7 +53,8 @@ class MixedBatch:
         self.offsets = np.concatenate([[0], np.cumsum([(6 * o * n + pad - 1) // pad * pad for n, o in self.shapes])]).astype(np.int64)
         self.algorithmic_bytes = int(sum(width * (3 * (n + 1) + n) + width * 3 * n * 2 * o for n, o in self.shapes))
         self.launches = 1
-        self.kernels = ["mixed (device-side bucketing + one persistent chunked launch per order)"]
+        self.kernels = ["mixed (device-side bucketing + ONE persistent launch of the lane-pair sweep for every order, S <= 64; "
+                        "longer trajectories: one persistent chunked launch per order)"]
 
     def run(self):
         self.prep.run()

@@ -387,3 +387,46 @@ def test_hip_against_the_60_digit_kkt_solution(csp):
             key = (c["order"], ("generic" if force else r.kernel.split("_")[0]) + ("+path" if c["path_weight"] else ""))
             worst[key] = max(worst.get(key, 0.0), pp)
     print("HIP vs the 60-digit KKT solution, worst per-power error by (order, kernel family):", worst)
+
+
+@pytest.mark.gpu
+def test_mixed_entry_lane_pair_sweep_against_the_chunked_kernels(tmp_path):
+    """csp_minsnap_solve_mixed serves trajectories of up to 64 segments with the lane-pair sweep (minsnap_twist_impl.h: two
+    forward sweeps and one backward sweep in blocks) and CSP_MIXED_TWIST=0 puts them on the chunked kernels
+    (substructuring): two different factorisation orders of the same system.  The library reads the switch once, so each
+    setting runs in its own process; fp64 storage, orders 2..5, every segment count 1..64, per-trajectory boundary
+    conditions; agreement per power at the level two HIP kernel families reach elsewhere (order 5: its conditioning)."""
+    import subprocess, sys, os
+    script = r'''
+import importlib, sys
+import numpy as np
+sys.path.insert(0, ".")
+csp = importlib.import_module("cs-pathplan_amd")
+g = np.random.default_rng(77)
+lens = np.concatenate([np.arange(1, 65), g.integers(1, 65, size=700)])
+orders = np.concatenate([np.repeat([2, 3, 4, 5], 16), g.integers(2, 6, size=700)]).astype(np.int32)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+wp = np.concatenate([np.cumsum(g.normal(size=(n + 1, 3)), axis=0) + g.uniform(-10, 10, 3) for n in lens])
+tm = g.uniform(0.5, 2.0, size=int(off[-1]))
+bc = g.normal(size=(len(lens), 4, 3))
+r = csp.solve_mixed(orders, wp, tm, off, bc=bc, vel_zero_weight=0.25, want_status=True)
+np.savez(sys.argv[1], co=np.asarray(r.coeffs), cf=np.asarray(r.coeff_offsets), st=np.asarray(r.status), orders=orders, lens=lens)
+'''
+    out = {}
+    for mask in ("0", "15"):
+        path = str(tmp_path / ("m%s.npz" % mask))
+        env = dict(os.environ, CSP_MIXED_TWIST=mask)
+        p = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, p.stderr[-3000:]
+        out[mask] = np.load(path)
+    a, b = out["0"], out["15"]
+    assert np.array_equal(a["cf"], b["cf"]) and np.array_equal(a["st"], b["st"]) and not a["st"].any()
+    worst = 0.0
+    for i, (o, n) in enumerate(zip(a["orders"], a["lens"])):
+        lo = int(a["cf"][i])
+        x = a["co"][lo:lo + n * 6 * o].reshape(n, 3, 2 * o)
+        y = b["co"][lo:lo + n * 6 * o].reshape(n, 3, 2 * o)
+        pp, _ = synth.parity_gate(y, x, 5e-5 if o == 5 else 1e-8, ("lane-pair sweep vs chunked", i, int(o), int(n)))
+        worst = max(worst, pp)
+    print("lane-pair sweep vs chunked kernels, per power: %.2e" % worst)

@@ -1,0 +1,15 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p /tmp/twp
+for m in 0 15; do
+export CSP_MIXED_TWIST=$m
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tw_prof_m$m -o tw -- python3 tools/twist_probe.py 65536 f32 --child $m /tmp/twp/m$m > gpurun_out/tw_prof_m$m.log 2>&1 || exit 1
+done
+python - <<'PY'
+import csv, glob
+for m in (0, 15):
+    f = glob.glob(f"gpurun_out/tw_prof_m{m}/**/*kernel_stats.csv", recursive=True)
+    print("mask", m, f)
+    for row in csv.DictReader(open(f[0])):
+        print("  %-90s calls=%s avg_us=%.1f" % (row["Name"][:90], row["Calls"], float(row["AverageNs"]) / 1e3))
+PY
