@@ -29,7 +29,7 @@ struct TwistCostOrder {
     unsigned char key_at[4 * MIXED_NCLS];
 };
 constexpr TwistCostOrder make_twist_cost_order() {
-    constexpr int W[4] = {42, 62, 100, 205};   // relative time of one step at orders 2..5 (tools/twist_probe.py)
+    constexpr int W[4] = {42, 62, 100, 205};   // relative time of one step at orders 2..5 (tools/twist_probe.py); listing the classes order by order instead measured the same
     TwistCostOrder c{};
     int cost[4 * MIXED_NCLS] = {};
     for (int key = 0; key < 4 * MIXED_NCLS; ++key) {
