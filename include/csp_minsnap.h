@@ -85,7 +85,7 @@ enum { CSP_MEM_HOST = 0, CSP_MEM_DEVICE = 1 };
                                   chunked, span and generic kernels test every stored coefficient                       */
 #define CSP_TRAJ_NOT_SPD 2     /* a pivot of the free-derivative Hessian R_PP was <= 0              */
 #define CSP_TRAJ_SKIPPED 4     /* csp_minsnap_solve_mixed only: the trajectory was NOT solved (its order is outside 2..5
-                                  or its segment count outside 1..256); its coefficient block is left untouched (zero-filled with CSP_MEM_HOST) */
+                                  or its segment count outside 1..min(256, max_segments)); its coefficient block is left untouched (zero-filled with CSP_MEM_HOST) */
 
 typedef struct csp_minsnap_desc {
     uint32_t abi_version;       /* CSP_MINSNAP_ABI_VERSION                                       */
@@ -179,9 +179,14 @@ int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *
  *   coeff_offsets_out : optional [B+1] int64, the offsets above (computed on the device); [B] = the total
  *   status      : optional [B] int32 CSP_TRAJ_* bits; trajectories outside the served range get CSP_TRAJ_SKIPPED
  *   workspace   : >= csp_minsnap_mixed_workspace_bytes(desc) bytes of device memory (CSP_MEM_DEVICE); NULL/0 with CSP_MEM_HOST
- * Per trajectory the arithmetic is csp_minsnap_solve_batch's workspace-free kernel for that order and length class.
- * CSP_MEM_DEVICE: asynchronous on `hip_stream` (the per-order launches run on internal streams forked from and joined
- * back into it).  CSP_MEM_HOST: staged through the cached arena, synchronous. */
+ *                 (it holds the bucketing tables and the checkpoint slots of the solve below: up to 0.43 MB per persistent
+ *                 workgroup at max_segments = 64, 220 MB from B = 16384 on; less for shorter trajectories)
+ * Trajectories of up to 64 segments are solved by a sequential twisted block-LDL^T sweep, two lanes per trajectory, in
+ * blocks of segments whose factors are recomputed from checkpoints (cs-pathplan_amd/csrc/minsnap_twist_impl.h: the arithmetic
+ * of the register-resident fixed-size kernels), every order in ONE persistent launch; longer ones (65..256 segments) by
+ * csp_minsnap_solve_batch's workspace-free chunked kernel, one launch per order.  A trajectory longer than
+ * desc->max_segments is reported CSP_TRAJ_SKIPPED.
+ * CSP_MEM_DEVICE: asynchronous on `hip_stream`.  CSP_MEM_HOST: staged through the cached arena, synchronous. */
 int csp_minsnap_solve_mixed(const csp_minsnap_desc *desc, const int32_t *orders, const void *waypoints, const void *times,
                             const void *bc, void *coeffs, int64_t *coeff_offsets_out, int32_t *status,
                             void *workspace, size_t workspace_bytes, void *hip_stream);
