@@ -26,6 +26,10 @@
 
 #include <type_traits>
 
+#ifndef CSP_TWIST_DIRECT
+#define CSP_TWIST_DIRECT 1   // 1: every lane stores its own records; 0: through a staging tile, transposed (A/B)
+#endif
+
 namespace csp {
 namespace twist {
 
@@ -210,7 +214,7 @@ template <int O, typename IO, bool BOTTOM, bool STATUS> struct Role {
 // first, reads the second); s_coef[row]: element offset of row's coefficient block; ck: this (workgroup, role)'s checkpoints.
 template <int O, typename IO, bool BOTTOM, bool STATUS>
 __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S, int rows, int64_t bb, int64_t seg0, char *tile,
-                                           double *x_mine, const double *x_other, const long long *s_coef, double *ck) {
+                                           double *x_mine, const double *x_other, const long long *s_coef, double *ck, long long coef0) {
     using RT = Role<O, IO, BOTTOM, STATUS>;
     using G = Geo<O>;
     using OG = Out<O, IO>;
@@ -265,6 +269,8 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
     double nanacc = 0.0;
     const int grp = lane / OG::LPR, lin = lane - grp * OG::LPR;
     typedef typename PieceT<IO, OG::PB>::type piece_t;
+    constexpr bool DIRECT = CSP_TWIST_DIRECT != 0;
+    IO *co_own = reinterpret_cast<IO *>(a.coeffs) + coef0;
     for (int blk = nb - 1; blk >= 0; --blk) {
         const int j0 = blk * K;
         ro.load_in(j0, in);
@@ -380,6 +386,7 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
                 tp[0] = Tj;
 #pragma unroll
                 for (int e = 1; e < N; ++e) tp[e] = tp[e - 1] * Tj;
+                const int g = BOTTOM ? S - 1 - j : j;   // global segment
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
                     double xs[N], xe[N], cc[M];
@@ -392,19 +399,29 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
                     const double Plo = in.P[kk + 1][ax], Phi = in.P[kk + 2][ax];
                     const double Ps = BOTTOM ? Phi : Plo, Pe = BOTTOM ? Plo : Phi;
                     fixedk::recover<O>(Ps, Pe - Ps, xs, xe, tp, ip, cc);
+                    if (DIRECT) {
+                        // the lane stores its own record: 64 partly written lines per instruction, completed by the next
+                        // instructions of the same lane (the L2 merges them) -- no tile, no transposed read-back, and no
+                        // predicate: the lanes beyond a ragged unit shadow row 0 (same inputs, same arithmetic), so they
+                        // store row 0's bytes a second time
+                        IO *dst = co_own + (long long)g * OG::REC + ax * M;
 #pragma unroll
-                    for (int i = 0; i < M; i += OG::EPP)
-                        *reinterpret_cast<piece_t *>(tile + lane * OG::ROWB + (ax * M + i) * (int)sizeof(IO)) = Pack<IO, OG::EPP>::make(cc + i);
+                        for (int i = 0; i < M; i += OG::EPP) *reinterpret_cast<piece_t *>(dst + i) = Pack<IO, OG::EPP>::make(cc + i);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < M; i += OG::EPP)
+                            *reinterpret_cast<piece_t *>(tile + lane * OG::ROWB + (ax * M + i) * (int)sizeof(IO)) = Pack<IO, OG::EPP>::make(cc + i);
+                    }
                     if (STATUS) {
 #pragma unroll
                         for (int i = 0; i < M; ++i) nanacc = __builtin_fma((double)(IO)cc[i], 0.0, nanacc);
                     }
                 }
+                if (!DIRECT) {
                 // LDS operations of one wave execute in order: no barrier, only compiler fences around the transposed read
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int g = BOTTOM ? S - 1 - j : j;   // global segment
 #pragma unroll
                 for (int it = 0; it < OG::NI; ++it) {
                     const int row = it * OG::RPI + grp;
@@ -416,6 +433,7 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int r = 0; r < N; ++r)
 #pragma unroll
@@ -507,13 +525,14 @@ __device__ __forceinline__ void run_unit(const GenericArgs &a, const int32_t *pe
     double *x0 = reinterpret_cast<double *>(lds + 2 * UL::TILEB), *x1 = reinterpret_cast<double *>(lds + 2 * UL::TILEB + UL::XCHB);
     const int64_t bb = perm[first + (lane < rows ? lane : 0)];   // idle lanes shadow row 0 (loads only)
     const int64_t seg0 = a.seg_off[bb];
-    if (wave == 0) s_coef[lane] = coef_off[bb];
+    const long long coef0 = coef_off[bb];
+    if (wave == 0) s_coef[lane] = coef0;
     if (S == 1) {
         if (wave == 0) single_segment<O, IO, STATUS>(a, lane, rows, bb, seg0, tile0, s_coef);
     } else if (wave == 0) {
-        twist_role<O, IO, false, STATUS>(a, lane, S, rows, bb, seg0, tile0, x0, x1, s_coef, ck);
+        twist_role<O, IO, false, STATUS>(a, lane, S, rows, bb, seg0, tile0, x0, x1, s_coef, ck, coef0);
     } else {
-        twist_role<O, IO, true, STATUS>(a, lane, S, rows, bb, seg0, tile1, x1, x0, s_coef, ck);
+        twist_role<O, IO, true, STATUS>(a, lane, S, rows, bb, seg0, tile1, x1, x0, s_coef, ck, coef0);
     }
 }
 

@@ -17,7 +17,7 @@ template <int O> struct Geo {
     // large one pushes the factors K * (N*N + 3N) doubles beyond the 256 architectural registers into AGPR copies and scratch --
     // and in ONE kernel for all orders the spills of one order slow the others down as well.
 #ifndef CSP_TWIST_K5
-#define CSP_TWIST_K5 2
+#define CSP_TWIST_K5 4
 #endif
 #ifndef CSP_TWIST_K4
 #define CSP_TWIST_K4 6

@@ -430,3 +430,48 @@ np.savez(sys.argv[1], co=np.asarray(r.coeffs), cf=np.asarray(r.coeff_offsets), s
         pp, _ = synth.parity_gate(y, x, 5e-5 if o == 5 else 1e-8, ("lane-pair sweep vs chunked", i, int(o), int(n)))
         worst = max(worst, pp)
     print("lane-pair sweep vs chunked kernels, per power: %.2e" % worst)
+
+
+@pytest.mark.gpu
+def test_mixed_entry_status_bits_and_declared_maximum(csp):
+    """The lane-pair sweep behind csp_minsnap_solve_mixed reports per trajectory: a NaN waypoint -> CSP_TRAJ_NONFINITE on that
+    trajectory only (its neighbours in the same 64-trajectory work unit are untouched); a trajectory longer than the declared
+    max_segments -> CSP_TRAJ_SKIPPED, its block left alone; fp32 and fp64 storage."""
+    import torch
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64):
+        lens = np.concatenate([np.full(130, 12), np.full(70, 40), [9]])
+        orders = np.resize(np.array([3, 4, 5, 2], dtype=np.int32), len(lens))
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        wp = np.cumsum(rng.normal(size=(int(off[-1]) + len(lens), 3)), axis=0).astype(dt)
+        tm = rng.uniform(0.5, 2.0, size=int(off[-1])).astype(dt)
+        bad = 37
+        wp[off[bad] + bad + 5, 1] = np.nan
+        d = [torch.from_numpy(x).cuda() for x in (orders, wp, tm, off)]
+        p = csp.PreparedMixed(d[0], d[1], d[2], d[3], want_status=True, max_segments=40)
+        clean_wp = wp.copy()
+        clean_wp[off[bad] + bad + 5, 1] = 0.0
+        q = csp.PreparedMixed(d[0], torch.from_numpy(clean_wp).cuda(), d[2], d[3], want_status=True, max_segments=40)
+        p.out.zero_(); q.out.zero_()
+        p.run(); q.run()
+        torch.cuda.synchronize()
+        st = p.status.cpu().numpy()
+        assert st[bad] & csp.TRAJ_NONFINITE and not np.delete(st, bad).any(), (dt, st[bad], np.flatnonzero(st))
+        assert not q.status.cpu().numpy().any()
+        cof = p.coeff_offsets.cpu().numpy()
+        a, b = p.out.cpu().numpy(), q.out.cpu().numpy()
+        keep = np.ones(a.size, bool)
+        keep[cof[bad]:cof[bad + 1]] = False
+        assert np.array_equal(a[keep], b[keep])
+        # declared maximum below the longest trajectory
+        r = csp.PreparedMixed(d[0], torch.from_numpy(clean_wp).cuda(), d[2], d[3], want_status=True, max_segments=12)
+        r.out.fill_(-3.0)
+        r.run()
+        torch.cuda.synchronize()
+        st = r.status.cpu().numpy()
+        long_ones = lens > 12
+        assert (st[long_ones] == csp.TRAJ_SKIPPED).all() and not st[~long_ones].any()
+        o = r.out.cpu().numpy()
+        i = int(np.flatnonzero(long_ones)[0])
+        assert (o[cof[i]:cof[i + 1]] == -3.0).all()
+        assert np.array_equal(o[cof[0]:cof[1]], b[cof[0]:cof[1]])
