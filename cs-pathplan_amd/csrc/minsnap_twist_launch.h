@@ -11,11 +11,11 @@ constexpr int HSMAX = SMAX / 2;   // segments per role
 
 template <int O> struct Geo {
     static constexpr int N = O - 1, M = 2 * O;
-    // Segments per block, measured (tools/twist_prof.sh, B = 65536 of one order, kernel time): order 4: K = 2 / 4 / 6 / 8 ->
-    // 191 / 136 / 117 / 156 us; order 5: K = 2 / 3 -> 276 / 326 us; order 3: K = 4 / 8 / 12 -> 97 / 80-88 / 128 us.  A small K
-    // pays a block start (checkpoint + inputs: one exposed memory round trip, ~1.5 us for a lone wave) every K segments; a
-    // large one pushes the factors K * (N*N + 3N) doubles beyond the 256 architectural registers into AGPR copies and scratch --
-    // and in ONE kernel for all orders the spills of one order slow the others down as well.
+    // Segments per block, measured (tools/twist_prof.sh, B = 65536 of one order, kernel time; DESIGN.md 10.3b has the table):
+    // order 3: 8 of 4 / 8 / 12; order 4: 6 of 2 / 4 / 6 / 8; order 5: 4 of 2 / 3 / 4 / 6.  A small K pays a block start (checkpoint +
+    // inputs: one exposed memory round trip for a lone wave) every K segments; a large one pushes the factors K * (N*N + 3N)
+    // doubles beyond the 256 architectural registers into AGPR copies and scratch -- and in ONE kernel for all orders the
+    // spills of one order slow the others down as well.
 #ifndef CSP_TWIST_K5
 #define CSP_TWIST_K5 4
 #endif
