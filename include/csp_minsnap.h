@@ -179,8 +179,8 @@ int csp_minsnap_solve_multi(const csp_minsnap_desc *desc, int n, const int64_t *
  *   coeff_offsets_out : optional [B+1] int64, the offsets above (computed on the device); [B] = the total
  *   status      : optional [B] int32 CSP_TRAJ_* bits; trajectories outside the served range get CSP_TRAJ_SKIPPED
  *   workspace   : >= csp_minsnap_mixed_workspace_bytes(desc) bytes of device memory (CSP_MEM_DEVICE); NULL/0 with CSP_MEM_HOST
- *                 (it holds the bucketing tables and the checkpoint slots of the solve below: up to 0.43 MB per persistent
- *                 workgroup at max_segments = 64, 220 MB from B = 16384 on; less for shorter trajectories)
+ *                 (it holds the bucketing tables and the checkpoint slots of the solve below: up to 0.2 MB per persistent
+ *                 workgroup at max_segments = 64, 103 MB from B = 16384 on; less for shorter trajectories)
  * Trajectories of up to 64 segments are solved by a sequential twisted block-LDL^T sweep, two lanes per trajectory, in
  * blocks of segments whose factors are recomputed from checkpoints (cs-pathplan_amd/csrc/minsnap_twist_impl.h: the arithmetic
  * of the register-resident fixed-size kernels), every order in ONE persistent launch; longer ones (65..256 segments) by
