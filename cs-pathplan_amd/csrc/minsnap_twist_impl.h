@@ -549,10 +549,12 @@ __global__ void __launch_bounds__(128) minsnap_twist_kernel(GenericArgs a, const
     __shared__ __attribute__((aligned(16))) char lds[unit_lds_bytes<IO>()];
     __shared__ long long s_coef[64];
     __shared__ int s_ustart[NK + 1];
+    __shared__ int s_bstart[4][MIXED_NCLS + 1];
     __shared__ int s_u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int q = tid; q <= NK; q += 128) s_ustart[q] = tab->tw_ustart[q];
+    for (int q = tid; q < 4 * (MIXED_NCLS + 1); q += 128) s_bstart[q / (MIXED_NCLS + 1)][q % (MIXED_NCLS + 1)] = tab->bucket_start[q / (MIXED_NCLS + 1)][q % (MIXED_NCLS + 1)];
     __syncthreads();
     const int total = s_ustart[NK];
     double *ck = ckws + ((size_t)blockIdx.x * 2 + wave) * ck_role_doubles;
@@ -566,8 +568,8 @@ __global__ void __launch_bounds__(128) minsnap_twist_kernel(GenericArgs a, const
         const int key = g_cost_order.key_at[p];
         const int oi = key / MIXED_NCLS, k = key % MIXED_NCLS;
         const int S = SMAX - k;
-        const int first = __builtin_amdgcn_readfirstlane(tab->bucket_start[oi][k] + (u - s_ustart[p]) * 64);
-        const int left_in_bucket = __builtin_amdgcn_readfirstlane(tab->bucket_start[oi][k + 1]) - first;
+        const int first = __builtin_amdgcn_readfirstlane(s_bstart[oi][k] + (u - s_ustart[p]) * 64);
+        const int left_in_bucket = __builtin_amdgcn_readfirstlane(s_bstart[oi][k + 1]) - first;
         const int rows = left_in_bucket < 64 ? left_in_bucket : 64;
         switch (oi) {
             case 0: run_unit<2, IO, STATUS>(a, perm, coef_off, lds, s_coef, ck, wave, lane, S, first, rows); break;
@@ -576,6 +578,8 @@ __global__ void __launch_bounds__(128) minsnap_twist_kernel(GenericArgs a, const
             default: run_unit<5, IO, STATUS>(a, perm, coef_off, lds, s_coef, ck, wave, lane, S, first, rows); break;
         }
         fixedk::lds_barrier();   // tiles, exchange areas and s_coef are reused by the next unit
+        // (claiming one unit AHEAD, to hide the counter's round trip, was measured: every workgroup then holds a second unit
+        // from t = 0 on, the one with the heaviest first unit included -- 179 -> 217 us)
         if (tid == 0) s_u = atomicAdd(&tab->next_unit, 1) + (int)gridDim.x;
         __syncthreads();
         u = s_u;
