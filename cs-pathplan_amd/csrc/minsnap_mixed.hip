@@ -99,15 +99,15 @@ __global__ void __launch_bounds__(PT) plan_kernel(MixedTable *tab, int32_t *hist
     __shared__ int total[NKEY];
     const int tid = threadIdx.x;
     // per key: exclusive scan over the blocks of that key's counts (in place: hist_blk becomes the block's offset inside its
-    // bucket); loads batched 32 at a time
+    // bucket); loads batched 64 at a time
     {
         int run = 0;
-        for (int64_t b0 = 0; b0 < nblk; b0 += 32) {   // 32 loads in flight per round trip (B = 65536: two round trips)
-            int v[32];
+        for (int64_t b0 = 0; b0 < nblk; b0 += 64) {   // 64 loads in flight per round trip (B = 65536: one round trip)
+            int v[64];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = b0 + q < nblk ? hist_blk[(b0 + q) * NKEY + tid] : 0;
+            for (int q = 0; q < 64; ++q) v[q] = b0 + q < nblk ? hist_blk[(b0 + q) * NKEY + tid] : 0;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
+            for (int q = 0; q < 64; ++q) {
                 if (b0 + q < nblk) hist_blk[(b0 + q) * NKEY + tid] = run;
                 run += v[q];
             }
