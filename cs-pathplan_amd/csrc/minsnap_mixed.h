@@ -28,12 +28,13 @@ struct MixedTable {
 struct TwistCostOrder {
     unsigned char key_at[4 * MIXED_NCLS];
 };
+// relative time of one step at orders 2..5 (tools/twist_probe.py); listing the classes order by order instead measured the same
+constexpr int TWIST_STEP_COST[4] = {42, 62, 100, 205};
 constexpr TwistCostOrder make_twist_cost_order() {
-    constexpr int W[4] = {42, 62, 100, 205};   // relative time of one step at orders 2..5 (tools/twist_probe.py); listing the classes order by order instead measured the same
     TwistCostOrder c{};
     int cost[4 * MIXED_NCLS] = {};
     for (int key = 0; key < 4 * MIXED_NCLS; ++key) {
-        cost[key] = W[key / MIXED_NCLS] * (MIXED_NCLS - key % MIXED_NCLS);
+        cost[key] = TWIST_STEP_COST[key / MIXED_NCLS] * (MIXED_NCLS - key % MIXED_NCLS);
         c.key_at[key] = (unsigned char)key;
     }
     for (int i = 1; i < 4 * MIXED_NCLS; ++i) {   // insertion sort, descending, stable

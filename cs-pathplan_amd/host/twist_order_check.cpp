@@ -9,10 +9,9 @@
 int main() {
     constexpr csp::TwistCostOrder c = csp::make_twist_cost_order();
     static_assert(sizeof(c.key_at) == 4 * csp::MIXED_NCLS, "one position per (order, S) class");
-    constexpr int W[4] = {42, 62, 100, 205};
     for (int p = 0; p < 4 * csp::MIXED_NCLS; ++p) {
         const int key = c.key_at[p], o = key / csp::MIXED_NCLS + 2, S = csp::MIXED_NCLS - key % csp::MIXED_NCLS;
-        std::printf("%d %d %d %d\n", p, o, S, W[o - 2] * S);
+        std::printf("%d %d %d %d\n", p, o, S, csp::TWIST_STEP_COST[o - 2] * S);
     }
     return 0;
 }
