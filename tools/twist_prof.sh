@@ -1,3 +1,6 @@
+# Kernel-level timeline of csp_minsnap_solve_mixed with the lane-pair sweep (CSP_MIXED_TWIST=15) and with the chunked kernels only (=0):
+# one rocprofv3 kernel trace per setting over tools/twist_probe.py's five batches (orders 4 / 3 / 5 / 2 alone, then the C5 mix).
+# Run ON the GPU box: gpurun -- bash tools/twist_prof.sh ; then python tools/twist_prof_read.py here.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p /tmp/twp
