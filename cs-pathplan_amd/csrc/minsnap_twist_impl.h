@@ -16,7 +16,9 @@
 // As in the fixed-size kernels a trajectory is split at waypoint ceil(S/2) between the two waves of a workgroup (the bottom
 // role walks the time-reversed second half: reversed waypoints, odd derivatives negated) and the halves meet once through
 // LDS.  The device-side bucketing (minsnap_mixed.hip) sorts by (order, S), so S is uniform inside a work unit of 64
-// trajectories and every loop bound is a scalar.
+// trajectories and every loop bound is a scalar.  Every lane stores its own records, 16 (8) bytes per instruction (no staging
+// tile: at this kernel's ~1.4 TB/s of output the L2 merges the partly written lines, and a lone wave per SIMD cannot hide the
+// tile's LDS round trips -- the opposite of the path kernels).
 //
 // Per trajectory the arithmetic is the fixed-size kernels' (same functions, same order of operations).
 #pragma once
@@ -38,9 +40,9 @@ using fixedk::SmallSpd;
 using fixedk::ee_of;
 using fixedk::seg_make;
 
-// Output geometry: a (trajectory, segment) record of 6*O elements leaves through a lane-major LDS tile and is read back
-// transposed, LPR lanes per record in pieces of PB bytes (16 where the record is a whole number of them: blocks start
-// 16-byte aligned, minsnap_mixed.hip block_elems; 8 for fp32 records of odd order).
+// Output geometry: a (trajectory, segment) record of 6*O elements leaves in pieces of PB bytes (16 where the record is a whole
+// number of them: blocks start 16-byte aligned, minsnap_mixed.hip block_elems; 8 for fp32 records of odd order).  The tile
+// geometry (LPR lanes per record, read back transposed) serves one-segment trajectories and the CSP_TWIST_DIRECT=0 build.
 template <int O, typename IO> struct Out {
     static constexpr int REC = 6 * O;
     static constexpr int RECB = REC * (int)sizeof(IO);
