@@ -91,9 +91,13 @@ template <int O, typename IO, bool BOTTOM, bool STATUS> struct Role {
     const IO *wp, *tm;    // this trajectory's first waypoint / first segment time
     int S, HS;            // uniform
     double vw;
-    double bv[3], ba[3];  // boundary velocity / acceleration of THIS role's outer end, in its orientation
+    const IO *bcp;        // boundary conditions [4][3] of this trajectory (v0, v1, a0, a1)
 
-    __device__ __forceinline__ double bc_at(int r, int ax) const { return r == 0 ? bv[ax] : r == 1 ? ba[ax] : 0.0; }
+    // boundary velocity / acceleration of THIS role's outer end, in its orientation -- read where they are needed (the first
+    // block of each pass and the very last step) instead of held: twelve registers for the life of the unit otherwise
+    __device__ __forceinline__ double bc_at(int r, int ax) const {
+        return r == 0 ? (BOTTOM ? -(double)bcp[1 * 3 + ax] : (double)bcp[0 * 3 + ax]) : r == 1 ? (BOTTOM ? (double)bcp[3 * 3 + ax] : (double)bcp[2 * 3 + ax]) : 0.0;
+    }
 
     __device__ __forceinline__ void load_raw(int j0, RawIn<K, IO> &raw) const {
 #pragma unroll
@@ -152,9 +156,8 @@ template <int O, typename IO, bool BOTTOM, bool STATUS> struct Role {
     // (RELEFT: rebuilt here from its time).  The test against HS is a real branch on purpose: it ends the scheduling region
     // once per segment (minsnap_fixed_path_impl.h has the measurements).
     template <bool STORE, bool RELEFT>
-    __device__ __forceinline__ void forward(int j0, const BlockIn<K> &in, double (&W)[N][N], double (&z)[N][3], double (&ipL)[M],
+    __device__ __forceinline__ void forward(int j0, const BlockIn<K> &in, double (&W)[N][N], double (&z)[N][3],
                                             double (&dPl)[3], bool &spd, double (&Wst)[K][N][N], double (&zst)[K][N][3]) const {
-        if (RELEFT && j0 >= 1) ladder(in.T[0], ipL);
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const int j = j0 + kk;
@@ -166,6 +169,10 @@ template <int O, typename IO, bool BOTTOM, bool STATUS> struct Role {
                     // afterwards): two whole Segs at once are 160 registers at order 5
                     double Sm[N][N], R[N][N + 3];   // right-hand sides: [C_j | y_j]
                     {
+                        // the left segment's ladder is rebuilt from its time (one reciprocal, M - 2 products) rather than
+                        // carried over from the step before: M doubles less across the solve
+                        double ipL[M];
+                        ladder(in.T[kk], ipL);
                         Seg<O> left;
                         seg_of(ipL, left);
 #pragma unroll
@@ -204,8 +211,6 @@ template <int O, typename IO, bool BOTTOM, bool STATUS> struct Role {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < M; ++e) ipL[e] = ipR[e];
-#pragma unroll
                 for (int ax = 0; ax < 3; ++ax) dPl[ax] = in.P[kk + 2][ax] - in.P[kk + 1][ax];
             }
         }
@@ -227,21 +232,12 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
     ro.wp = (const IO *)a.wp + (seg0 + bb) * 3;
     ro.tm = (const IO *)a.times + seg0;
     ro.vw = a.vw_per ? a.vw_per[bb] : a.vel_zero_weight;
-    {
-        const IO *bc = (const IO *)a.bc + (a.bc_per_traj ? bb * 12 : 0);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            ro.bv[ax] = BOTTOM ? -(double)bc[1 * 3 + ax] : (double)bc[0 * 3 + ax];
-            ro.ba[ax] = BOTTOM ? (double)bc[3 * 3 + ax] : (double)bc[2 * 3 + ax];
-        }
-    }
+    ro.bcp = (const IO *)a.bc + (a.bc_per_traj ? bb * 12 : 0);
     const int HS = ro.HS, nb = (HS + K - 1) / K;
 
     double W[N][N], z[N][3], dPl[3] = {0.0, 0.0, 0.0};
     double Wst[K][N][N], zst[K][N][3];
-    double ipL[M];
-#pragma unroll
-    for (int e = 0; e < M; ++e) ipL[e] = 1.0;
+    const IO t_last = ro.tm[BOTTOM ? S - ro.HS : ro.HS - 1];   // the segment next to the middle waypoint: its ladder is needed once
     bool spd = true;
     BlockIn<K> in;
 #pragma unroll
@@ -254,7 +250,7 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
     // ---- pass 1: forward over blocks 0 .. nb-2, a checkpoint at every block boundary ----
     for (int blk = 0; blk < nb - 1; ++blk) {
         ro.load_in(blk * K, in);
-        ro.template forward<false, false>(blk * K, in, W, z, ipL, dPl, spd, Wst, zst);
+        ro.template forward<false, false>(blk * K, in, W, z, dPl, spd, Wst, zst);
         double *c = ck + (size_t)blk * G::CKD * 64 + lane;
         int e = 0;
 #pragma unroll
@@ -298,11 +294,13 @@ __device__ __forceinline__ void twist_role(const GenericArgs &a, int lane, int S
                 }
             }
         }
-        ro.template forward<true, true>(j0, in, W, z, ipL, dPl, spd, Wst, zst);
+        ro.template forward<true, true>(j0, in, W, z, dPl, spd, Wst, zst);
         if (blk == nb - 1) {
             // Schur carry of this half onto the middle waypoint, exchanged through LDS (minsnap_fixed_impl.h)
             double Cm[N][N], cm[N][3];
             Seg<O> left;
+            double ipL[M];
+            RT::ladder((double)t_last, ipL);
             ro.seg_of(ipL, left);
 #pragma unroll
             for (int r = 0; r < N; ++r) {
