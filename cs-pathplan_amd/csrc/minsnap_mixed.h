@@ -28,8 +28,9 @@ struct MixedTable {
 struct TwistCostOrder {
     unsigned char key_at[4 * MIXED_NCLS];
 };
-// relative time of one step at orders 2..5 (tools/twist_probe.py); listing the classes order by order instead measured the same
-constexpr int TWIST_STEP_COST[4] = {42, 62, 100, 205};
+// relative time of one work unit per segment at orders 2..5 (tools/twist_unit_time.py: 60 / 90 / 128 / 210 us at 64 segments);
+// listing the classes order by order instead measured the same
+constexpr int TWIST_STEP_COST[4] = {47, 70, 100, 164};
 constexpr TwistCostOrder make_twist_cost_order() {
     TwistCostOrder c{};
     int cost[4 * MIXED_NCLS] = {};
